@@ -1,0 +1,333 @@
+"""ctypes binding of libptops.so (include/ptops.h) for torch tensors.
+
+This is the only place the package touches the native library.  Every wrapper checks
+device / dtype / contiguity (the reference's extensions check nothing,
+extensions/chamfer_dist/chamfer.cu:147-171), launches on torch's CURRENT stream (the reference
+launches on the default stream) and raises RuntimeError with the library's message
+on a non-zero status.
+
+There is no CPU fallback: a missing library or a non-GPU tensor raises.  Tests (and only
+tests / the bench's cpu_baseline leg) may install a replacement backend object with
+`set_backend_for_testing`, e.g. one that routes to the CPU oracle to exercise the Python
+plumbing on a machine without a GPU; the package itself never imports the oracle.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptops.so")
+
+_lib = None
+_test_backend = None
+
+
+class PtopsError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    c_int, c_void, c_size = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    P = c_void  # raw device pointers travel as integers
+    sig = {
+        "ptops_abi_version": (c_int, []),
+        "ptops_last_error": (ctypes.c_char_p, []),
+        "ptops_chamfer_forward_workspace_bytes": (c_size, [c_int] * 3),
+        "ptops_chamfer_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
+        "ptops_chamfer_backward": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P]),
+        "ptops_furthest_point_sample": (c_int, [P, c_int, c_int, c_int, P, P]),
+        "ptops_gather_forward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_gather_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_knn": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_index_points_forward": (c_int, [P, P] + [c_int] * 5 + [P, P]),
+        "ptops_index_points_backward": (c_int, [P, P] + [c_int] * 5 + [P, P]),
+        "ptops_edge_group_forward": (c_int, [P, P, P] + [c_int] * 5 + [P, P]),
+        "ptops_edge_group_backward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
+        "ptops_gather_max_forward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
+        "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = (
+    "ptops_abi_version", "ptops_last_error", "ptops_chamfer_forward_workspace_bytes",
+    "ptops_chamfer_forward", "ptops_chamfer_backward", "ptops_furthest_point_sample",
+    "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
+    "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
+    "ptops_gather_max_forward", "ptops_gather_max_backward",
+)
+
+
+def load():
+    """dlopen libptops.so (built in-tree by imgadapointr_amd/csrc/Makefile); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtopsError(
+                f"{LIB_PATH} is missing: build it with `make -C imgadapointr_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def set_backend_for_testing(backend):
+    """Install (or, with None, remove) a replacement for the functions of this module.
+
+    Test infrastructure only: `backend` must provide the same function names as this module
+    (chamfer_forward, ..., gather_max_backward) taking/returning torch tensors."""
+    global _test_backend
+    _test_backend = backend
+
+
+def backend_for_testing():
+    return _test_backend
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check(t, name, dtype, ndim):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise PtopsError(f"{name}: tensor is on {t.device}; libptops runs on the GPU only "
+                         "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _call(fn_name, *args):
+    lib = load()
+    rc = getattr(lib, fn_name)(*args)
+    if rc != 0:
+        raise PtopsError(f"{fn_name} failed ({rc}): {lib.ptops_last_error().decode()}")
+
+
+def _same_device(*ts):
+    d = ts[0].device
+    for t in ts[1:]:
+        if t.device != d:
+            raise ValueError(f"tensors on different devices: {d} vs {t.device}")
+    return d
+
+
+# ------------------------------------------------------------------------------------------
+def chamfer_forward(xyz1, xyz2):
+    """chamfer.forward (extensions/chamfer_dist/chamfer_cuda.cpp:22-25)."""
+    if _test_backend is not None:
+        return _test_backend.chamfer_forward(xyz1, xyz2)
+    _check(xyz1, "xyz1", torch.float32, 3)
+    _check(xyz2, "xyz2", torch.float32, 3)
+    dev = _same_device(xyz1, xyz2)
+    B, n, c = xyz1.shape
+    B2, m, c2 = xyz2.shape
+    if c != 3 or c2 != 3 or B != B2:
+        raise ValueError(f"chamfer_forward: expected [B,n,3] and [B,m,3], got {tuple(xyz1.shape)} {tuple(xyz2.shape)}")
+    with torch.cuda.device(dev):
+        dist1 = torch.empty((B, n), dtype=torch.float32, device=dev)
+        dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
+        idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
+        idx2 = torch.empty((B, m), dtype=torch.int32, device=dev)
+        wsb = load().ptops_chamfer_forward_workspace_bytes(B, n, m)
+        ws = torch.empty((wsb // 8,), dtype=torch.int64, device=dev) if wsb else None
+        _call("ptops_chamfer_forward", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist1), _ptr(dist2),
+              _ptr(idx1), _ptr(idx2), _ptr(ws) if ws is not None else None, _stream(xyz1))
+    return dist1, dist2, idx1, idx2
+
+
+def chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
+    """chamfer.backward (extensions/chamfer_dist/chamfer_cuda.cpp:27-34)."""
+    if _test_backend is not None:
+        return _test_backend.chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+    _check(xyz1, "xyz1", torch.float32, 3)
+    _check(xyz2, "xyz2", torch.float32, 3)
+    _check(idx1, "idx1", torch.int32, 2)
+    _check(idx2, "idx2", torch.int32, 2)
+    _check(grad_dist1, "grad_dist1", torch.float32, 2)
+    _check(grad_dist2, "grad_dist2", torch.float32, 2)
+    dev = _same_device(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    if tuple(idx1.shape) != (B, n) or tuple(idx2.shape) != (B, m) or \
+            tuple(grad_dist1.shape) != (B, n) or tuple(grad_dist2.shape) != (B, m):
+        raise ValueError("chamfer_backward: idx/grad shapes do not match the clouds")
+    with torch.cuda.device(dev):
+        g1 = torch.empty_like(xyz1)
+        g2 = torch.empty_like(xyz2)
+        _call("ptops_chamfer_backward", _ptr(xyz1), _ptr(xyz2), _ptr(idx1), _ptr(idx2),
+              _ptr(grad_dist1), _ptr(grad_dist2), B, n, m, _ptr(g1), _ptr(g2), _stream(xyz1))
+    return g1, g2
+
+
+def furthest_point_sample(xyz, npoint):
+    """pointnet2_utils.furthest_point_sample: xyz [B,N,3] -> int32 [B,npoint]."""
+    if _test_backend is not None:
+        return _test_backend.furthest_point_sample(xyz, npoint)
+    _check(xyz, "xyz", torch.float32, 3)
+    B, N, c = xyz.shape
+    if c != 3:
+        raise ValueError(f"furthest_point_sample: expected [B,N,3], got {tuple(xyz.shape)}")
+    with torch.cuda.device(xyz.device):
+        idx = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
+        _call("ptops_furthest_point_sample", _ptr(xyz), B, N, int(npoint), _ptr(idx), _stream(xyz))
+    return idx
+
+
+def gather_forward(feat, idx):
+    """gather_operation forward: feat [B,C,N], idx int32 [B,npoint] -> [B,C,npoint]."""
+    if _test_backend is not None:
+        return _test_backend.gather_forward(feat, idx)
+    _check(feat, "features", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 2)
+    dev = _same_device(feat, idx)
+    B, C, N = feat.shape
+    npoint = idx.shape[1]
+    with torch.cuda.device(dev):
+        out = torch.empty((B, C, npoint), dtype=torch.float32, device=dev)
+        _call("ptops_gather_forward", _ptr(feat), _ptr(idx), B, C, N, npoint, _ptr(out), _stream(feat))
+    return out
+
+
+def gather_backward(grad_out, idx, N):
+    if _test_backend is not None:
+        return _test_backend.gather_backward(grad_out, idx, N)
+    _check(grad_out, "grad_out", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 2)
+    dev = _same_device(grad_out, idx)
+    B, C, npoint = grad_out.shape
+    with torch.cuda.device(dev):
+        g = torch.empty((B, C, int(N)), dtype=torch.float32, device=dev)
+        _call("ptops_gather_backward", _ptr(grad_out), _ptr(idx), B, C, int(N), npoint, _ptr(g),
+              _stream(grad_out))
+    return g
+
+
+def knn(k, xyz, new_xyz):
+    """Fused knn_point: xyz [B,N,3] candidates, new_xyz [B,S,3] queries -> int32 [B,S,k]."""
+    if _test_backend is not None:
+        return _test_backend.knn(k, xyz, new_xyz)
+    _check(xyz, "xyz", torch.float32, 3)
+    _check(new_xyz, "new_xyz", torch.float32, 3)
+    dev = _same_device(xyz, new_xyz)
+    B, N, c = xyz.shape
+    B2, S, c2 = new_xyz.shape
+    if c != 3 or c2 != 3 or B != B2:
+        raise ValueError(f"knn: expected [B,N,3] and [B,S,3], got {tuple(xyz.shape)} {tuple(new_xyz.shape)}")
+    with torch.cuda.device(dev):
+        idx = torch.empty((B, S, int(k)), dtype=torch.int32, device=dev)
+        _call("ptops_knn", _ptr(xyz), _ptr(new_xyz), B, N, S, int(k), _ptr(idx), _stream(xyz))
+    return idx
+
+
+def index_points_forward(points, idx):
+    """points [B,N,C], idx int32 [B,S,k] -> [B,S,k,C]."""
+    if _test_backend is not None:
+        return _test_backend.index_points_forward(points, idx)
+    _check(points, "points", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    dev = _same_device(points, idx)
+    B, N, C = points.shape
+    _, S, k = idx.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((B, S, k, C), dtype=torch.float32, device=dev)
+        _call("ptops_index_points_forward", _ptr(points), _ptr(idx), B, N, C, S, k, _ptr(out),
+              _stream(points))
+    return out
+
+
+def index_points_backward(grad_out, idx, N):
+    if _test_backend is not None:
+        return _test_backend.index_points_backward(grad_out, idx, N)
+    _check(grad_out, "grad_out", torch.float32, 4)
+    _check(idx, "idx", torch.int32, 3)
+    dev = _same_device(grad_out, idx)
+    B, S, k, C = grad_out.shape
+    with torch.cuda.device(dev):
+        g = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
+        _call("ptops_index_points_backward", _ptr(grad_out), _ptr(idx), B, int(N), C, S, k, _ptr(g),
+              _stream(grad_out))
+    return g
+
+
+def edge_group_forward(x_k, x_q, idx):
+    """x_k [B,C,Nk], x_q [B,C,Nq], idx int32 [B,Nq,k] -> [B,2C,Nq,k]."""
+    if _test_backend is not None:
+        return _test_backend.edge_group_forward(x_k, x_q, idx)
+    _check(x_k, "x_k", torch.float32, 3)
+    _check(x_q, "x_q", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    dev = _same_device(x_k, x_q, idx)
+    B, C, Nk = x_k.shape
+    Nq = x_q.shape[2]
+    k = idx.shape[2]
+    if tuple(x_q.shape[:2]) != (B, C) or tuple(idx.shape[:2]) != (B, Nq):
+        raise ValueError("edge_group_forward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        out = torch.empty((B, 2 * C, Nq, k), dtype=torch.float32, device=dev)
+        _call("ptops_edge_group_forward", _ptr(x_k), _ptr(x_q), _ptr(idx), B, C, Nk, Nq, k, _ptr(out),
+              _stream(x_k))
+    return out
+
+
+def edge_group_backward(grad_out, idx, Nk):
+    if _test_backend is not None:
+        return _test_backend.edge_group_backward(grad_out, idx, Nk)
+    _check(grad_out, "grad_out", torch.float32, 4)
+    _check(idx, "idx", torch.int32, 3)
+    dev = _same_device(grad_out, idx)
+    B, C2, Nq, k = grad_out.shape
+    C = C2 // 2
+    with torch.cuda.device(dev):
+        gk = torch.empty((B, C, int(Nk)), dtype=torch.float32, device=dev)
+        gq = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
+        _call("ptops_edge_group_backward", _ptr(grad_out), _ptr(idx), B, C, int(Nk), Nq, k, _ptr(gk),
+              _ptr(gq), _stream(grad_out))
+    return gk, gq
+
+
+def gather_max_forward(p, idx):
+    """p [B,N,C], idx int32 [B,S,k] -> (max [B,S,C], arg int32 [B,S,C])."""
+    if _test_backend is not None:
+        return _test_backend.gather_max_forward(p, idx)
+    _check(p, "p", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    dev = _same_device(p, idx)
+    B, N, C = p.shape
+    _, S, k = idx.shape
+    with torch.cuda.device(dev):
+        out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, S, C), dtype=torch.int32, device=dev)
+        _call("ptops_gather_max_forward", _ptr(p), _ptr(idx), B, N, C, S, k, _ptr(out), _ptr(arg),
+              _stream(p))
+    return out, arg
+
+
+def gather_max_backward(grad_out, arg, N):
+    if _test_backend is not None:
+        return _test_backend.gather_max_backward(grad_out, arg, N)
+    _check(grad_out, "grad_out", torch.float32, 3)
+    _check(arg, "arg", torch.int32, 3)
+    dev = _same_device(grad_out, arg)
+    B, S, C = grad_out.shape
+    with torch.cuda.device(dev):
+        g = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
+        _call("ptops_gather_max_backward", _ptr(grad_out), _ptr(arg), B, int(N), C, S, _ptr(g),
+              _stream(grad_out))
+    return g

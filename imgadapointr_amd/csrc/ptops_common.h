@@ -1,0 +1,39 @@
+// Shared host-side helpers for libptops (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "ptops.h"
+
+#define PTOPS_API extern "C" __attribute__((visibility("default")))
+
+namespace ptops {
+
+// Thread-local message behind ptops_last_error().
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PTOPS_ELAUNCH;
+  }
+  return PTOPS_OK;
+}
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+constexpr int kNumCU = 256;   // MI355X
+constexpr int kWave = 64;
+
+}  // namespace ptops
+
+#define PTOPS_REQUIRE(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      ptops::set_error(__VA_ARGS__);    \
+      return PTOPS_EINVAL;              \
+    }                                   \
+  } while (0)

@@ -1,0 +1,124 @@
+/*
+ * ptops.h — C ABI of libptops, the MI355X (gfx950) point-cloud primitive library
+ * that sits under the AdaPoinTr completion hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, explicit sizes and an explicit
+ * hipStream_t (passed as void* so that this header needs no HIP include), does no
+ * hidden allocation, keeps no global state, launches on the given stream and
+ * returns an int status (PTOPS_OK or a negative PTOPS_E* code).  Scratch memory is
+ * caller-provided; the *_workspace_bytes helpers say how much.
+ *
+ * Each function names the reference interface it replaces (paths relative to the
+ * reference repository mmkuznecov/ImgAdaPoinTr).
+ *
+ * All point data is fp32, all indices int32, all tensors dense row-major.
+ */
+#ifndef PTOPS_H_
+#define PTOPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTOPS_OK 0
+#define PTOPS_EINVAL (-1)   /* bad size / null pointer / unsupported shape */
+#define PTOPS_ELAUNCH (-2)  /* the HIP runtime reported a launch error      */
+#define PTOPS_EALIGN (-3)   /* a pointer does not meet the stated alignment  */
+
+/* Library identification; ptops_last_error() returns a thread-local message for
+ * the most recent non-OK status on the calling thread. */
+int ptops_abi_version(void);
+const char* ptops_last_error(void);
+
+/* ---------------------------------------------------------------- Chamfer --
+ * Replaces chamfer.forward  (extensions/chamfer_dist/chamfer_cuda.cpp:22-25,
+ * kernel extensions/chamfer_dist/chamfer.cu:15-171).
+ *   xyz1 [B,n,3], xyz2 [B,m,3]  ->  dist1 [B,n], idx1 [B,n] (nearest point of
+ *   xyz2 for every point of xyz1: squared distance, index), dist2/idx2 [B,m] the
+ *   other way round.  Squared distance = fma(dz,dz, fma(dy,dy, dx*dx)) with
+ *   d* = candidate - query; ties resolve to the lowest candidate index.
+ * workspace: ptops_chamfer_forward_workspace_bytes(B,n,m) bytes, 8-byte aligned
+ *   (may be NULL when that function returns 0).                               */
+size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m);
+int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, int m,
+                          float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                          void* workspace, void* stream);
+
+/* Replaces chamfer.backward (extensions/chamfer_dist/chamfer_cuda.cpp:27-34,
+ * kernel extensions/chamfer_dist/chamfer.cu:173-229).
+ *   grad_xyz1 [B,n,3], grad_xyz2 [B,m,3] are fully overwritten (zeroed first).  */
+int ptops_chamfer_backward(const float* xyz1, const float* xyz2,
+                           const int32_t* idx1, const int32_t* idx2,
+                           const float* grad_dist1, const float* grad_dist2,
+                           int B, int n, int m,
+                           float* grad_xyz1, float* grad_xyz2, void* stream);
+
+/* ------------------------------------------------- farthest point sampling --
+ * Replaces pointnet2_ops.pointnet2_utils.furthest_point_sample (third-party,
+ * un-vendored; call sites models/base_blocks.py:550, utils/misc.py:37).
+ *   xyz [B,N,3] -> idx [B,npoint]; starts at index 0, running min-distance
+ *   initialised to 1e10, candidates with |p|^2 <= 1e-3 never selected, arg-max
+ *   ties resolve to the lowest index.  Because the selection order is
+ *   prefix-consistent, idx[:, :p] is the answer for npoint = p.               */
+int ptops_furthest_point_sample(const float* xyz, int B, int N, int npoint,
+                                int32_t* idx, void* stream);
+
+/* Replaces pointnet2_utils.gather_operation forward / backward
+ * (call sites models/base_blocks.py:555, utils/misc.py:38).
+ *   out[b,c,j] = feat[b,c,idx[b,j]];  feat [B,C,N], idx [B,npoint].
+ *   backward: grad_feat [B,C,N] is zeroed, then scatter-added.                */
+int ptops_gather_forward(const float* feat, const int32_t* idx, int B, int C, int N,
+                         int npoint, float* out, void* stream);
+int ptops_gather_backward(const float* grad_out, const int32_t* idx, int B, int C,
+                          int N, int npoint, float* grad_feat, void* stream);
+
+/* --------------------------------------------------------------------- kNN --
+ * Replaces knn_point + square_distance (models/Transformer_utils.py:19-51)
+ * without materialising the [B,S,N] matrix.
+ *   xyz [B,N,3] (candidates), new_xyz [B,S,3] (queries) -> idx [B,S,k]:
+ *   the k candidates with the smallest expansion-form squared distance
+ *   ((-2*(q.c) + |q|^2) + |c|^2, q.c = fma(qz,cz, fma(qy,cy, qx*cx))),
+ *   ordered by (distance, index) ascending.  Requires 1 <= k <= min(N, 64).   */
+int ptops_knn(const float* xyz, const float* new_xyz, int B, int N, int S, int k,
+              int32_t* idx, void* stream);
+
+/* Replaces index_points (models/Transformer_utils.py:53-69) for idx [B,S,k]:
+ *   out[b,s,j,:] = points[b, idx[b,s,j], :];  points [B,N,C] -> out [B,S,k,C].
+ *   backward: grad_points [B,N,C] zeroed then scatter-added.                   */
+int ptops_index_points_forward(const float* points, const int32_t* idx, int B, int N,
+                               int C, int S, int k, float* out, void* stream);
+int ptops_index_points_backward(const float* grad_out, const int32_t* idx, int B,
+                                int N, int C, int S, int k, float* grad_points,
+                                void* stream);
+
+/* --------------------------------------------------- DGCNN edge grouping ---
+ * Replaces the gather+concat half of DGCNN_Grouper.get_graph_feature
+ * (models/base_blocks.py:565-588).
+ *   x_k [B,C,Nk], x_q [B,C,Nq], idx [B,Nq,k] (neighbour ids into Nk) ->
+ *   out [B,2C,Nq,k]: channels [0,C) = x_k[:, c, idx] - x_q, [C,2C) = x_q.
+ *   backward: grad_xk [B,C,Nk] (zeroed, scatter-added), grad_xq [B,C,Nq].      */
+int ptops_edge_group_forward(const float* x_k, const float* x_q, const int32_t* idx,
+                             int B, int C, int Nk, int Nq, int k, float* out,
+                             void* stream);
+int ptops_edge_group_backward(const float* grad_out, const int32_t* idx, int B, int C,
+                              int Nk, int Nq, int k, float* grad_xk, float* grad_xq,
+                              void* stream);
+
+/* ----------------------------------------------- graph gather-max (fused) ---
+ * The neighbour half of DynamicGraphAttention (models/Transformer_utils.py:
+ * 811-817) after the exact split W.cat(v_j - q, q) = W1.v_j + (W2 - W1).q:
+ *   p [B,N,C] (= v @ W1^T), idx [B,S,k] -> out[b,s,c] = max_j p[b,idx[b,s,j],c],
+ *   arg[b,s,c] = the winning row id (first maximum).  backward routes grad_out
+ *   to grad_p[b,arg,c] (grad_p zeroed then scatter-added).                     */
+int ptops_gather_max_forward(const float* p, const int32_t* idx, int B, int N, int C,
+                             int S, int k, float* out, int32_t* arg, void* stream);
+int ptops_gather_max_backward(const float* grad_out, const int32_t* arg, int B, int N,
+                              int C, int S, float* grad_p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTOPS_H_ */

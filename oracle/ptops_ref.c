@@ -1,0 +1,390 @@
+/*
+ * ptops_ref.c — CPU ORACLE for libptops.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  Nothing under imgadapointr_amd/
+ * imports, links or falls back to it.
+ *
+ * It restates, in plain scalar C, the algorithms of the reference's CUDA-only /
+ * third-party operators so that the HIP kernels can be checked bit-for-bit (indices,
+ * distances) on identical inputs.  Each function cites the reference file:line it
+ * follows (paths relative to mmkuznecov/ImgAdaPoinTr).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - kNN / square_distance / index_points / edge grouping / graph attention are
+ *     pinned by golden vectors generated from the reference's own pure-torch code
+ *     (tests/golden/make_golden.py).
+ *   - Chamfer: the reference holds no known-answer vectors and its only
+ *     implementation is CUDA (not runnable here); pinned by the arithmetic stated in
+ *     chamfer.cu plus brute-force float64 cross-checks.  The fp32 contraction order
+ *     (mul, fma, fma) is what nvcc's default -fmad=true emits for
+ *     x*x + y*y + z*z; last-ulp parity with a CUDA build is therefore UNPINNED.
+ *   - FPS / gather_operation come from pointnet2_ops, which is not vendored and not
+ *     version-pinned by the reference: PARITY UNPINNED; this restatement is the
+ *     definition (start 0, 1e10 init, |p|^2 <= 1e-3 skip, lowest-index ties).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).  All fused
+ * multiply-adds are explicit fmaf() calls so that the compiler may not add or
+ * remove any.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define REF_API __attribute__((visibility("default")))
+
+REF_API int ref_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+REF_API void ref_set_num_threads(int t) {
+#ifdef _OPENMP
+  omp_set_num_threads(t);
+#else
+  (void)t;
+#endif
+}
+
+/* Squared distance exactly as chamfer.cu:40-43 evaluates it (candidate minus
+ * query, then x*x + y*y + z*z contracted left to right).                       */
+static inline float sqdist_direct(float qx, float qy, float qz, float cx, float cy,
+                                  float cz) {
+  float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* One direction of chamfer.cu:15-145: for every query j of `q` the minimum over
+ * all candidates k of `c`; the first candidate is taken unconditionally
+ * (chamfer.cu:45 `k == 0 ||`), later ones only on strict `<` (chamfer.cu:57), so
+ * the lowest index wins ties.  The 512-point tiling of the CUDA kernel changes
+ * nothing observable: its cross-tile update (chamfer.cu:137) is also strict.   */
+static void chamfer_one_way(const float* q, int nq, const float* c, int nc, float* dist,
+                            int32_t* idx) {
+  for (int j = 0; j < nq; ++j) {
+    const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+    float best = 0.0f;
+    int32_t best_i = 0;
+    for (int k = 0; k < nc; ++k) {
+      float d = sqdist_direct(qx, qy, qz, c[k * 3 + 0], c[k * 3 + 1], c[k * 3 + 2]);
+      if (k == 0 || d < best) {
+        best = d;
+        best_i = k;
+      }
+    }
+    dist[j] = best;
+    idx[j] = best_i;
+  }
+}
+
+/* chamfer_cuda_forward, chamfer.cu:147-171. */
+REF_API void ref_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, int m,
+                                 float* dist1, float* dist2, int32_t* idx1, int32_t* idx2) {
+  /* Parallel over (batch, direction, query block): pure function of inputs. */
+  const int QB = 256;
+  const int nb1 = (n + QB - 1) / QB, nb2 = (m + QB - 1) / QB;
+  const int per_b = nb1 + nb2;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < B * per_b; ++t) {
+    int b = t / per_b, r = t % per_b;
+    const float* a = xyz1 + (size_t)b * n * 3;
+    const float* c = xyz2 + (size_t)b * m * 3;
+    if (r < nb1) {
+      int j0 = r * QB, cnt = (j0 + QB <= n) ? QB : n - j0;
+      chamfer_one_way(a + (size_t)j0 * 3, cnt, c, m, dist1 + (size_t)b * n + j0,
+                      idx1 + (size_t)b * n + j0);
+    } else {
+      int j0 = (r - nb1) * QB, cnt = (j0 + QB <= m) ? QB : m - j0;
+      chamfer_one_way(c + (size_t)j0 * 3, cnt, a, n, dist2 + (size_t)b * m + j0,
+                      idx2 + (size_t)b * m + j0);
+    }
+  }
+}
+
+/* chamfer_dist_grad_kernel + chamfer_cuda_backward, chamfer.cu:173-229.  The CUDA
+ * kernel accumulates with atomicAdd in an unspecified order; here the order is
+ * fixed (pass 1 over xyz1 ascending, then pass 2 over xyz2 ascending), which is
+ * one of the orders the reference may produce.                                  */
+REF_API void ref_chamfer_backward(const float* xyz1, const float* xyz2, const int32_t* idx1,
+                                  const int32_t* idx2, const float* grad_dist1,
+                                  const float* grad_dist2, int B, int n, int m,
+                                  float* grad_xyz1, float* grad_xyz2) {
+  memset(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3);
+  memset(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    const float* a = xyz1 + (size_t)b * n * 3;
+    const float* c = xyz2 + (size_t)b * m * 3;
+    float* ga = grad_xyz1 + (size_t)b * n * 3;
+    float* gc = grad_xyz2 + (size_t)b * m * 3;
+    for (int pass = 0; pass < 2; ++pass) {
+      const float* p = pass ? c : a;
+      const float* o = pass ? a : c;
+      float* gp = pass ? gc : ga;
+      float* go = pass ? ga : gc;
+      const int32_t* idx = (pass ? idx2 + (size_t)b * m : idx1 + (size_t)b * n);
+      const float* gd = (pass ? grad_dist2 + (size_t)b * m : grad_dist1 + (size_t)b * n);
+      int cnt = pass ? m : n;
+      for (int j = 0; j < cnt; ++j) {
+        int j2 = idx[j];
+        float g = gd[j] * 2.0f;
+        for (int d = 0; d < 3; ++d) {
+          float v = g * (p[j * 3 + d] - o[j2 * 3 + d]);
+          gp[j * 3 + d] += v;
+          go[j2 * 3 + d] += -v;
+        }
+      }
+    }
+  }
+}
+
+/* pointnet2_ops furthest_point_sample (un-vendored third party; call sites
+ * models/base_blocks.py:550, utils/misc.py:37).  Definition restated in SURVEY
+ * §8a row a4: first pick is index 0; running minimum squared distance starts at
+ * 1e10; a candidate whose squared norm is <= 1e-3 is skipped (neither updated nor
+ * eligible); next pick = arg-max of the running minimum (start value -1, index 0),
+ * lowest index on ties.                                                          */
+REF_API void ref_furthest_point_sample(const float* xyz, int B, int N, int npoint,
+                                       int32_t* idx) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    const float* p = xyz + (size_t)b * N * 3;
+    int32_t* out = idx + (size_t)b * npoint;
+    float* mind = (float*)malloc(sizeof(float) * (size_t)N);
+    for (int k = 0; k < N; ++k) mind[k] = 1e10f;
+    int old = 0;
+    if (npoint > 0) out[0] = 0;
+    for (int j = 1; j < npoint; ++j) {
+      const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+      float best = -1.0f;
+      int besti = 0;
+      for (int k = 0; k < N; ++k) {
+        const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+        float mag = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+        if (mag <= 1e-3f) continue;
+        float d = sqdist_direct(x1, y1, z1, x2, y2, z2);
+        float d2 = d < mind[k] ? d : mind[k];
+        mind[k] = d2;
+        if (d2 > best) {
+          best = d2;
+          besti = k;
+        }
+      }
+      old = besti;
+      out[j] = old;
+    }
+    free(mind);
+  }
+}
+
+/* pointnet2_ops gather_operation forward (call sites base_blocks.py:555,
+ * misc.py:38): out[b,c,j] = feat[b,c,idx[b,j]].                                  */
+REF_API void ref_gather_forward(const float* feat, const int32_t* idx, int B, int C, int N,
+                                int npoint, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int bc = 0; bc < B * C; ++bc) {
+    int b = bc / C;
+    const float* f = feat + (size_t)bc * N;
+    const int32_t* id = idx + (size_t)b * npoint;
+    float* o = out + (size_t)bc * npoint;
+    for (int j = 0; j < npoint; ++j) o[j] = f[id[j]];
+  }
+}
+
+/* gather_operation backward: scatter-add of grad_out into a zeroed grad_feat. */
+REF_API void ref_gather_backward(const float* grad_out, const int32_t* idx, int B, int C,
+                                 int N, int npoint, float* grad_feat) {
+  memset(grad_feat, 0, sizeof(float) * (size_t)B * C * N);
+#pragma omp parallel for schedule(static)
+  for (int bc = 0; bc < B * C; ++bc) {
+    int b = bc / C;
+    float* g = grad_feat + (size_t)bc * N;
+    const int32_t* id = idx + (size_t)b * npoint;
+    const float* go = grad_out + (size_t)bc * npoint;
+    for (int j = 0; j < npoint; ++j) g[id[j]] += go[j];
+  }
+}
+
+/* square_distance, models/Transformer_utils.py:32-51, for C = 3:
+ *   dist = -2 * (src @ dst^T); dist += sum(src**2); dist += sum(dst**2)
+ * with src = the query, dst = the candidate (knn_point calls
+ * square_distance(new_xyz, xyz), Transformer_utils.py:28).  The BLAS accumulation
+ * order of the K=3 matmul is unspecified in the reference; here it is
+ * fma(z, z', fma(y, y', x*x')).  sum(v**2) is ((x*x + y*y) + z*z), no contraction. */
+static inline float sumsq3(float x, float y, float z) {
+  float a = x * x, b = y * y, c = z * z;
+  return (a + b) + c;
+}
+static inline float sqdist_expanded(float qx, float qy, float qz, float qq, float cx,
+                                    float cy, float cz, float cc) {
+  float dot = fmaf(qz, cz, fmaf(qy, cy, qx * cx));
+  float t = fmaf(-2.0f, dot, qq); /* == fl(fl(-2*dot) + qq): -2*dot is exact */
+  return t + cc;
+}
+
+REF_API void ref_square_distance(const float* src, const float* dst, int B, int N, int M,
+                                 float* out) {
+#pragma omp parallel for schedule(static)
+  for (int bn = 0; bn < B * N; ++bn) {
+    int b = bn / N;
+    const float* s = src + (size_t)bn * 3;
+    const float ss = sumsq3(s[0], s[1], s[2]);
+    const float* d = dst + (size_t)b * M * 3;
+    float* o = out + (size_t)bn * M;
+    for (int k = 0; k < M; ++k) {
+      float dd = sumsq3(d[k * 3], d[k * 3 + 1], d[k * 3 + 2]);
+      o[k] = sqdist_expanded(s[0], s[1], s[2], ss, d[k * 3], d[k * 3 + 1], d[k * 3 + 2], dd);
+    }
+  }
+}
+
+/* knn_point, models/Transformer_utils.py:19-30: the k smallest entries of the row
+ * (torch.topk largest=False, sorted=False — order unspecified in the reference).
+ * Here the result is ordered by (distance, index) ascending, which also fixes the
+ * membership on exact ties.                                                      */
+REF_API void ref_knn(const float* xyz, const float* new_xyz, int B, int N, int S, int k,
+                     int32_t* idx) {
+#pragma omp parallel for schedule(static)
+  for (int bs = 0; bs < B * S; ++bs) {
+    int b = bs / S;
+    const float* q = new_xyz + (size_t)bs * 3;
+    const float qq = sumsq3(q[0], q[1], q[2]);
+    const float* c = xyz + (size_t)b * N * 3;
+    float bd[64];
+    int32_t bi[64];
+    int cnt = 0;
+    for (int j = 0; j < N; ++j) {
+      float cc = sumsq3(c[j * 3], c[j * 3 + 1], c[j * 3 + 2]);
+      float d = sqdist_expanded(q[0], q[1], q[2], qq, c[j * 3], c[j * 3 + 1], c[j * 3 + 2], cc);
+      /* insertion keeping (d, index) ascending; equal d keeps the earlier index first */
+      if (cnt < k || d < bd[cnt - 1]) {
+        int pos = cnt < k ? cnt : k - 1;
+        while (pos > 0 && bd[pos - 1] > d) {
+          bd[pos] = bd[pos - 1];
+          bi[pos] = bi[pos - 1];
+          --pos;
+        }
+        bd[pos] = d;
+        bi[pos] = j;
+        if (cnt < k) ++cnt;
+      }
+    }
+    for (int j = 0; j < k; ++j) idx[(size_t)bs * k + j] = bi[j];
+  }
+}
+
+/* index_points, models/Transformer_utils.py:53-69, for idx of shape [B,S,k]. */
+REF_API void ref_index_points_forward(const float* points, const int32_t* idx, int B, int N,
+                                      int C, int S, int k, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int bs = 0; bs < B * S; ++bs) {
+    int b = bs / S;
+    for (int j = 0; j < k; ++j) {
+      const float* src = points + ((size_t)b * N + idx[(size_t)bs * k + j]) * C;
+      memcpy(out + ((size_t)bs * k + j) * C, src, sizeof(float) * (size_t)C);
+    }
+  }
+}
+
+REF_API void ref_index_points_backward(const float* grad_out, const int32_t* idx, int B,
+                                       int N, int C, int S, int k, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)B * N * C);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int s = 0; s < S; ++s)
+      for (int j = 0; j < k; ++j) {
+        size_t e = ((size_t)b * S + s) * k + j;
+        float* g = grad_points + ((size_t)b * N + idx[e]) * C;
+        const float* go = grad_out + e * C;
+        for (int c = 0; c < C; ++c) g[c] += go[c];
+      }
+}
+
+/* DGCNN_Grouper.get_graph_feature, models/base_blocks.py:565-588 (gather + concat):
+ * out[b, c, q, j] = x_k[b, c, idx[b,q,j]] - x_q[b, c, q]   for c in [0,C)
+ * out[b, C+c, q, j] = x_q[b, c, q].                                              */
+REF_API void ref_edge_group_forward(const float* x_k, const float* x_q, const int32_t* idx,
+                                    int B, int C, int Nk, int Nq, int k, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int bc = 0; bc < B * C; ++bc) {
+    int b = bc / C, c = bc % C;
+    const float* xk = x_k + (size_t)bc * Nk;
+    const float* xq = x_q + (size_t)bc * Nq;
+    float* o0 = out + ((size_t)b * 2 * C + c) * Nq * k;
+    float* o1 = out + ((size_t)b * 2 * C + C + c) * Nq * k;
+    const int32_t* id = idx + (size_t)b * Nq * k;
+    for (int q = 0; q < Nq; ++q)
+      for (int j = 0; j < k; ++j) {
+        o0[(size_t)q * k + j] = xk[id[(size_t)q * k + j]] - xq[q];
+        o1[(size_t)q * k + j] = xq[q];
+      }
+  }
+}
+
+REF_API void ref_edge_group_backward(const float* grad_out, const int32_t* idx, int B, int C,
+                                     int Nk, int Nq, int k, float* grad_xk, float* grad_xq) {
+  memset(grad_xk, 0, sizeof(float) * (size_t)B * C * Nk);
+#pragma omp parallel for schedule(static)
+  for (int bc = 0; bc < B * C; ++bc) {
+    int b = bc / C, c = bc % C;
+    float* gk = grad_xk + (size_t)bc * Nk;
+    float* gq = grad_xq + (size_t)bc * Nq;
+    const float* g0 = grad_out + ((size_t)b * 2 * C + c) * Nq * k;
+    const float* g1 = grad_out + ((size_t)b * 2 * C + C + c) * Nq * k;
+    const int32_t* id = idx + (size_t)b * Nq * k;
+    for (int q = 0; q < Nq; ++q) {
+      float acc = 0.0f;
+      for (int j = 0; j < k; ++j) {
+        float a = g0[(size_t)q * k + j];
+        gk[id[(size_t)q * k + j]] += a;
+        acc += g1[(size_t)q * k + j] - a;
+      }
+      gq[q] = acc;
+    }
+  }
+}
+
+/* Neighbour half of DynamicGraphAttention (models/Transformer_utils.py:811-817)
+ * after the split W.cat(v_j - q, q) = W1.v_j + (W2-W1).q and the monotonicity of
+ * LeakyReLU: out[b,s,c] = max_j p[b, idx[b,s,j], c], first maximum wins.         */
+REF_API void ref_gather_max_forward(const float* p, const int32_t* idx, int B, int N, int C,
+                                    int S, int k, float* out, int32_t* arg) {
+#pragma omp parallel for schedule(static)
+  for (int bs = 0; bs < B * S; ++bs) {
+    int b = bs / S;
+    const int32_t* id = idx + (size_t)bs * k;
+    for (int c = 0; c < C; ++c) {
+      float best = p[((size_t)b * N + id[0]) * C + c];
+      int32_t bi = id[0];
+      for (int j = 1; j < k; ++j) {
+        float v = p[((size_t)b * N + id[j]) * C + c];
+        if (v > best) {
+          best = v;
+          bi = id[j];
+        }
+      }
+      out[(size_t)bs * C + c] = best;
+      arg[(size_t)bs * C + c] = bi;
+    }
+  }
+}
+
+REF_API void ref_gather_max_backward(const float* grad_out, const int32_t* arg, int B, int N,
+                                     int C, int S, float* grad_p) {
+  memset(grad_p, 0, sizeof(float) * (size_t)B * N * C);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int s = 0; s < S; ++s)
+      for (int c = 0; c < C; ++c) {
+        size_t e = ((size_t)b * S + s) * C + c;
+        grad_p[((size_t)b * N + arg[e]) * C + c] += grad_out[e];
+      }
+}

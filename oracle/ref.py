@@ -1,0 +1,202 @@
+"""numpy front-end of the CPU oracle (oracle/ptops_ref.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under imgadapointr_amd/ does.  Every function takes and returns
+C-contiguous numpy arrays (float32 / int32) and calls the C restatement through
+ctypes.  `build()` compiles the shared object with gcc (see oracle/Makefile).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libptops_ref.so")
+_lib = None
+
+_f = ctypes.POINTER(ctypes.c_float)
+_i = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    """Compile oracle/libptops_ref.so if missing or older than its sources."""
+    srcs = [os.path.join(_HERE, n) for n in os.listdir(_HERE) if n.endswith(".c")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libptops_ref.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.ref_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _fp(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_i)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def num_threads():
+    return int(lib().ref_num_threads())
+
+
+def set_num_threads(t):
+    lib().ref_set_num_threads(ctypes.c_int(int(t)))
+
+
+def chamfer_forward(xyz1, xyz2):
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.empty((B, n), np.float32)
+    d2 = np.empty((B, m), np.float32)
+    i1 = np.empty((B, n), np.int32)
+    i2 = np.empty((B, m), np.int32)
+    lib().ref_chamfer_forward(_fp(xyz1), _fp(xyz2), B, n, m, _fp(d1), _fp(d2), _ip(i1), _ip(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, idx1, idx2, g1, g2):
+    xyz1, xyz2, g1, g2 = _f32(xyz1), _f32(xyz2), _f32(g1), _f32(g2)
+    idx1, idx2 = _i32(idx1), _i32(idx2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    ga = np.empty_like(xyz1)
+    gb = np.empty_like(xyz2)
+    lib().ref_chamfer_backward(_fp(xyz1), _fp(xyz2), _ip(idx1), _ip(idx2), _fp(g1), _fp(g2),
+                               B, n, m, _fp(ga), _fp(gb))
+    return ga, gb
+
+
+def chamfer_l1(xyz1, xyz2):
+    """ChamferDistanceL1.forward, extensions/chamfer_dist/__init__.py:64-84 (float64 means)."""
+    d1, d2, _, _ = chamfer_forward(xyz1, xyz2)
+    return (np.sqrt(d1).astype(np.float32).mean(dtype=np.float64)
+            + np.sqrt(d2).astype(np.float32).mean(dtype=np.float64)) / 2
+
+
+def chamfer_l2(xyz1, xyz2):
+    """ChamferDistanceL2.forward, extensions/chamfer_dist/__init__.py:28-44."""
+    d1, d2, _, _ = chamfer_forward(xyz1, xyz2)
+    return d1.mean(dtype=np.float64) + d2.mean(dtype=np.float64)
+
+
+def furthest_point_sample(xyz, npoint):
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    idx = np.empty((B, npoint), np.int32)
+    lib().ref_furthest_point_sample(_fp(xyz), B, N, int(npoint), _ip(idx))
+    return idx
+
+
+def gather_forward(feat, idx):
+    feat, idx = _f32(feat), _i32(idx)
+    B, C, N = feat.shape
+    npoint = idx.shape[1]
+    out = np.empty((B, C, npoint), np.float32)
+    lib().ref_gather_forward(_fp(feat), _ip(idx), B, C, N, npoint, _fp(out))
+    return out
+
+
+def gather_backward(grad_out, idx, N):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    B, C, npoint = grad_out.shape
+    g = np.empty((B, C, N), np.float32)
+    lib().ref_gather_backward(_fp(grad_out), _ip(idx), B, C, int(N), npoint, _fp(g))
+    return g
+
+
+def square_distance(src, dst):
+    src, dst = _f32(src), _f32(dst)
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = np.empty((B, N, M), np.float32)
+    lib().ref_square_distance(_fp(src), _fp(dst), B, N, M, _fp(out))
+    return out
+
+
+def knn(k, xyz, new_xyz):
+    """knn_point(nsample, xyz, new_xyz) -> int32 [B,S,k] ordered by (distance, index)."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    assert 1 <= k <= min(N, 64)
+    idx = np.empty((B, S, k), np.int32)
+    lib().ref_knn(_fp(xyz), _fp(new_xyz), B, N, S, int(k), _ip(idx))
+    return idx
+
+
+def index_points_forward(points, idx):
+    points, idx = _f32(points), _i32(idx)
+    B, N, C = points.shape
+    _, S, k = idx.shape
+    out = np.empty((B, S, k, C), np.float32)
+    lib().ref_index_points_forward(_fp(points), _ip(idx), B, N, C, S, k, _fp(out))
+    return out
+
+
+def index_points_backward(grad_out, idx, N):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    B, S, k, C = grad_out.shape
+    g = np.empty((B, int(N), C), np.float32)
+    lib().ref_index_points_backward(_fp(grad_out), _ip(idx), B, int(N), C, S, k, _fp(g))
+    return g
+
+
+def edge_group_forward(x_k, x_q, idx):
+    x_k, x_q, idx = _f32(x_k), _f32(x_q), _i32(idx)
+    B, C, Nk = x_k.shape
+    Nq = x_q.shape[2]
+    k = idx.shape[2]
+    out = np.empty((B, 2 * C, Nq, k), np.float32)
+    lib().ref_edge_group_forward(_fp(x_k), _fp(x_q), _ip(idx), B, C, Nk, Nq, k, _fp(out))
+    return out
+
+
+def edge_group_backward(grad_out, idx, Nk):
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    B, C2, Nq, k = grad_out.shape
+    C = C2 // 2
+    gk = np.empty((B, C, int(Nk)), np.float32)
+    gq = np.empty((B, C, Nq), np.float32)
+    lib().ref_edge_group_backward(_fp(grad_out), _ip(idx), B, C, int(Nk), Nq, k, _fp(gk), _fp(gq))
+    return gk, gq
+
+
+def gather_max_forward(p, idx):
+    p, idx = _f32(p), _i32(idx)
+    B, N, C = p.shape
+    _, S, k = idx.shape
+    out = np.empty((B, S, C), np.float32)
+    arg = np.empty((B, S, C), np.int32)
+    lib().ref_gather_max_forward(_fp(p), _ip(idx), B, N, C, S, k, _fp(out), _ip(arg))
+    return out, arg
+
+
+def gather_max_backward(grad_out, arg, N):
+    grad_out, arg = _f32(grad_out), _i32(arg)
+    B, S, C = grad_out.shape
+    g = np.empty((B, int(N), C), np.float32)
+    lib().ref_gather_max_backward(_fp(grad_out), _ip(arg), B, int(N), C, S, _fp(g))
+    return g

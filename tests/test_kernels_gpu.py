@@ -1,0 +1,175 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle on seeded inputs.
+
+Indices and distances must be BIT-EXACT; scatter-add backward passes (floating-point
+accumulation order differs between the GPU's atomics and the oracle's loops) are compared
+with a tight tolerance written next to each check.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, B, n, kind="uniform"):
+    if kind == "uniform":
+        return (rng.random((B, n, 3), dtype=np.float32) - 0.5)
+    if kind == "shell":  # points on a random-radius sphere shell, 25 % trailing zero rows
+        v = rng.standard_normal((B, n, 3)).astype(np.float32)
+        v /= np.linalg.norm(v, axis=-1, keepdims=True) + 1e-9
+        v *= (0.3 + 0.2 * rng.random((B, n, 1), dtype=np.float32))
+        v[:, n - n // 4:, :] = 0.0
+        return v.astype(np.float32)
+    if kind == "dups":  # heavy duplication -> exact distance ties
+        base = (rng.random((B, max(n // 8, 1), 3), dtype=np.float32) - 0.5)
+        idx = rng.integers(0, base.shape[1], size=(B, n))
+        return np.take_along_axis(base, idx[..., None].repeat(3, -1), axis=1).astype(np.float32)
+    raise ValueError(kind)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+CHAMFER_CASES = [
+    (2, 64, 128, "uniform"), (4, 2048, 2048, "uniform"), (3, 512, 16384, "uniform"),
+    (2, 16384, 16384, "uniform"), (1, 1, 1, "uniform"), (1, 1, 777, "uniform"), (2, 300, 17, "uniform"),
+    (2, 1000, 999, "dups"), (2, 2048, 4096, "shell"), (1, 5000, 3, "uniform"), (32, 512, 2048, "uniform"),
+]
+
+
+@pytest.mark.parametrize("B,n,m,kind", CHAMFER_CASES)
+def test_chamfer_forward_bit_exact(native, ref, B, n, m, kind):
+    rng = np.random.default_rng(B * 1000003 + n * 101 + m)
+    a, b = _cloud(rng, B, n, kind), _cloud(rng, B, m, kind)
+    d1, d2, i1, i2 = native.chamfer_forward(_t(a), _t(b))
+    r1, r2, j1, j2 = ref.chamfer_forward(a, b)
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), r1.view(np.uint32))
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), r2.view(np.uint32))
+    assert np.array_equal(i1.cpu().numpy(), j1)
+    assert np.array_equal(i2.cpu().numpy(), j2)
+
+
+def test_chamfer_identity(native):
+    x = torch.rand(2, 1000, 3, device="cuda") - 0.5
+    d1, d2, i1, i2 = native.chamfer_forward(x, x.clone())
+    assert float(d1.abs().max()) == 0.0 and float(d2.abs().max()) == 0.0
+    ar = torch.arange(1000, device="cuda", dtype=torch.int32).expand(2, -1)
+    assert torch.equal(i1, ar) and torch.equal(i2, ar)
+
+
+@pytest.mark.parametrize("B,n,m,kind", [(2, 64, 128, "uniform"), (4, 2048, 2048, "uniform"),
+                                        (2, 512, 16384, "uniform"), (2, 1000, 999, "dups")])
+def test_chamfer_backward(native, ref, B, n, m, kind):
+    rng = np.random.default_rng(7 + n + m)
+    a, b = _cloud(rng, B, n, kind), _cloud(rng, B, m, kind)
+    _, _, j1, j2 = ref.chamfer_forward(a, b)
+    g1 = rng.standard_normal((B, n)).astype(np.float32)
+    g2 = rng.standard_normal((B, m)).astype(np.float32)
+    ga, gb = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2))
+    ra, rb = ref.chamfer_backward(a, b, j1, j2, g1, g2)
+    # atomics sum in a different order than the oracle's loops: a few ulps of the largest term
+    np.testing.assert_allclose(ga.cpu().numpy(), ra, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), rb, rtol=1e-5, atol=1e-5)
+
+
+FPS_CASES = [(2, 2048, 512, "uniform"), (3, 512, 256, "uniform"), (2, 2048, 256, "shell"), (2, 2048, 64, "shell"),
+             (1, 100, 100, "uniform"), (2, 1500, 300, "dups"), (1, 4096, 128, "uniform"), (1, 16384, 64, "uniform"),
+             (1, 700, 1, "uniform"), (2, 256, 16, "uniform")]
+
+
+@pytest.mark.parametrize("B,N,npoint,kind", FPS_CASES)
+def test_fps_exact(native, ref, B, N, npoint, kind):
+    rng = np.random.default_rng(N + npoint)
+    x = _cloud(rng, B, N, kind)
+    got = native.furthest_point_sample(_t(x), npoint).cpu().numpy()
+    want = ref.furthest_point_sample(x, npoint)
+    assert np.array_equal(got, want)
+
+
+def test_fps_all_zero_cloud(native, ref):
+    x = np.zeros((2, 512, 3), np.float32)  # every candidate is skipped -> index 0 repeated
+    got = native.furthest_point_sample(_t(x), 8).cpu().numpy()
+    assert np.array_equal(got, ref.furthest_point_sample(x, 8))
+    assert (got == 0).all()
+
+
+def test_fps_prefix_consistent(native):
+    x = torch.rand(2, 2048, 3, device="cuda") - 0.5
+    full = native.furthest_point_sample(x, 512)
+    assert torch.equal(full[:, :256], native.furthest_point_sample(x, 256))
+    assert torch.equal(full[:, :64], native.furthest_point_sample(x, 64))
+
+
+KNN_CASES = [(2, 2048, 2048, 16, "uniform"), (2, 2048, 512, 16, "uniform"), (2, 512, 512, 16, "uniform"),
+             (2, 512, 256, 16, "uniform"), (2, 256, 256, 8, "uniform"), (2, 256, 576, 8, "uniform"),
+             (2, 576, 64, 8, "uniform"), (2, 16384, 64, 32, "uniform"), (2, 2048, 2048, 16, "shell"),
+             (2, 1000, 333, 16, "dups"), (1, 70, 5, 64, "uniform"), (1, 16, 3, 16, "uniform"),
+             (1, 5000, 17, 1, "uniform"), (2, 3000, 100, 32, "dups")]
+
+
+@pytest.mark.parametrize("B,N,S,k,kind", KNN_CASES)
+def test_knn_exact(native, ref, B, N, S, k, kind):
+    rng = np.random.default_rng(N * 7 + S * 3 + k)
+    c, q = _cloud(rng, B, N, kind), _cloud(rng, B, S, kind)
+    got = native.knn(k, _t(c), _t(q)).cpu().numpy()
+    want = ref.knn(k, c, q)
+    assert np.array_equal(got, want)
+
+
+def test_gather_and_grad(native, ref):
+    rng = np.random.default_rng(3)
+    feat = rng.standard_normal((3, 35, 2048)).astype(np.float32)
+    idx = ref.furthest_point_sample(_cloud(rng, 3, 2048), 512)
+    out = native.gather_forward(_t(feat), _t(idx)).cpu().numpy()
+    assert np.array_equal(out, ref.gather_forward(feat, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    g = native.gather_backward(_t(go), _t(idx), 2048).cpu().numpy()
+    assert np.array_equal(g, ref.gather_backward(go, idx, 2048))  # FPS indices are unique: exact
+
+
+@pytest.mark.parametrize("B,N,C,S,k", [(2, 16384, 3, 64, 32), (2, 256, 384, 576, 8), (1, 100, 7, 33, 5)])
+def test_index_points(native, ref, B, N, C, S, k):
+    rng = np.random.default_rng(N + C)
+    pts = rng.standard_normal((B, N, C)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, S, k)).astype(np.int32)
+    out = native.index_points_forward(_t(pts), _t(idx)).cpu().numpy()
+    assert np.array_equal(out, ref.index_points_forward(pts, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    g = native.index_points_backward(_t(go), _t(idx), N).cpu().numpy()
+    np.testing.assert_allclose(g, ref.index_points_backward(go, idx, N), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,Nk,Nq,k", [(2, 8, 2048, 2048, 16), (2, 32, 2048, 512, 16), (2, 64, 512, 512, 16),
+                                         (2, 64, 512, 256, 16), (1, 5, 100, 37, 3), (1, 3, 50, 20, 8)])
+def test_edge_group(native, ref, B, C, Nk, Nq, k):
+    rng = np.random.default_rng(C + Nk + Nq)
+    xk = rng.standard_normal((B, C, Nk)).astype(np.float32)
+    xq = rng.standard_normal((B, C, Nq)).astype(np.float32)
+    idx = rng.integers(0, Nk, size=(B, Nq, k)).astype(np.int32)
+    out = native.edge_group_forward(_t(xk), _t(xq), _t(idx)).cpu().numpy()
+    assert np.array_equal(out, ref.edge_group_forward(xk, xq, idx))
+    go = rng.standard_normal(out.shape).astype(np.float32)
+    gk, gq = native.edge_group_backward(_t(go), _t(idx), Nk)
+    rk, rq = ref.edge_group_backward(go, idx, Nk)
+    np.testing.assert_allclose(gk.cpu().numpy(), rk, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gq.cpu().numpy(), rq, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,N,C,S,k", [(2, 256, 384, 256, 8), (2, 576, 384, 576, 8), (1, 50, 6, 20, 4)])
+def test_gather_max(native, ref, B, N, C, S, k):
+    rng = np.random.default_rng(N + S)
+    p = rng.standard_normal((B, N, C)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, S, k)).astype(np.int32)
+    out, arg = native.gather_max_forward(_t(p), _t(idx))
+    ro, ra = ref.gather_max_forward(p, idx)
+    assert np.array_equal(out.cpu().numpy(), ro)
+    assert np.array_equal(arg.cpu().numpy(), ra)
+    go = rng.standard_normal(ro.shape).astype(np.float32)
+    g = native.gather_max_backward(_t(go), _t(ra), N).cpu().numpy()
+    np.testing.assert_allclose(g, ref.gather_max_backward(go, ra, N), rtol=1e-5, atol=1e-5)
+
+
+def test_cpu_tensor_is_refused(native):
+    with pytest.raises(Exception):
+        native.chamfer_forward(torch.rand(1, 8, 3), torch.rand(1, 8, 3))
