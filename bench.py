@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: clouds/sec of one full AdaPoinTr train step on PCN-shaped synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + get_loss (denoise kNN + 3 Chamfer) + backward + gradient averaging (RCCL) +
+clip_grad_norm_(10) + AdamW step on one batch of 32 clouds per GPU (2048-point partial ->
+16384-point completion; BASELINE.json configs[1]), fp32 throughout, inputs resident in HBM.
+Rank 0 prints ONE JSON line.  It carries
+  roofline     — the dominant hand-written kernel (Chamfer 16384x16384 nearest-neighbour search):
+                 algorithmic FLOPs / average launch duration measured with events on the launching
+                 stream during the timed steps, against the fp32 vector peak; plus the same launch
+                 priced in algorithmic HBM bytes;
+  cpu_baseline — the same train step run on the host cores through the CPU oracle ("port": the
+                 reference has no CPU implementation of Chamfer / FPS), on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from imgadapointr_amd import _native  # noqa: E402
+from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
+from imgadapointr_amd.tools import builder  # noqa: E402
+from imgadapointr_amd.tools.runner import TrainStep  # noqa: E402
+from imgadapointr_amd.utils.config import cfg_from_yaml_file  # noqa: E402
+from imgadapointr_amd.utils.flat_ddp import FlatDDP  # noqa: E402
+
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add per squared distance
+N_PARTIAL, N_GT, BATCH = 2048, 16384, 32
+
+
+def load_cfg():
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        return cfg_from_yaml_file("cfgs/PCN_models/AdaPoinTr.yaml")
+    finally:
+        os.chdir(cwd)
+
+
+class ChamferProbe:
+    """Times every Chamfer forward launch of a given shape with events on the launching stream."""
+
+    def __init__(self, n, m):
+        self.shape = (n, m)
+        self.events = []
+        self.orig = _native.chamfer_forward
+        self.enabled = False
+
+    def __call__(self, xyz1, xyz2):
+        if self.enabled and (xyz1.shape[1], xyz2.shape[1]) == self.shape:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()          # current stream == the stream libptops launches on
+            out = self.orig(xyz1, xyz2)
+            e.record()
+            self.events.append((s, e, xyz1.shape[0]))
+            return out
+        return self.orig(xyz1, xyz2)
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = [s.elapsed_time(e) for s, e, _ in self.events]
+        B = self.events[0][2]
+        avg_ms = sum(ms) / len(ms)
+        n, m = self.shape
+        flops = FLOP_PER_PAIR * 2.0 * B * n * m
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        alg_bytes = 20.0 * B * (n + m)
+        return {
+            "bound": "valu-fp32", "kernel": "chamfer_nn_kernel (16384x16384 nearest-neighbour, both directions)",
+            "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": None,
+            "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "hbm": {"achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
+        }
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The same train step on the host cores through the CPU oracle, B=2 (BASELINE configs[0])."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import ref as oracle
+    from oracle_backend import OracleBackend
+    oracle.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    oracle.set_num_threads(cores)
+    _native.set_backend_for_testing(OracleBackend())
+    try:
+        torch.manual_seed(0)
+        model = build_model_from_cfg(cfg.model)
+        model.train()
+        opt = builder.build_optimizer(model, cfg)
+        step = TrainStep(model, opt)
+        B = 2
+        partial = torch.rand(B, N_PARTIAL, 3) - 0.5
+        gt = torch.rand(B, N_GT, 3) - 0.5
+        step(partial, gt)  # warm-up
+        t0 = time.time()
+        n = 0
+        while True:
+            step(partial, gt)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 12:
+                break
+        dt = time.time() - t0
+    finally:
+        _native.set_backend_for_testing(None)
+    return {"value": round(B * n / dt, 3), "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full train steps (fwd+loss+bwd+clip+AdamW) at bs={B}, 2048->16384, eager fp32 torch on "
+                      f"{cores} threads, Chamfer/FPS/kNN/gathers through the CPU oracle (OpenMP)",
+            "ms_per_step": round(dt / n * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="clouds per GPU (the metric is quoted at 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+    _native.load()
+
+    cfg = load_cfg()
+    torch.manual_seed(0)                     # identical weights on every rank
+    model = build_model_from_cfg(cfg.model).to(device)
+    model.train()
+    wrapped = FlatDDP(model) if world > 1 else model
+    optimizer = builder.build_optimizer(wrapped, cfg)
+    step = TrainStep(wrapped, optimizer, getattr(cfg, "grad_norm_clip", 10), 1)
+
+    torch.manual_seed(0 + rank)              # per-rank data, main.py:57 of the reference
+    B = args.batch
+    partial = (torch.rand(B, N_PARTIAL, 3) - 0.5).to(device)
+    gt = (torch.rand(B, N_GT, 3) - 0.5).to(device)
+
+    probe = ChamferProbe(N_GT, N_GT)
+    _native.chamfer_forward = probe
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(partial, gt)
+    barrier()
+    probe.enabled = True
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step(partial, gt)
+    barrier()
+    dt = time.perf_counter() - t0
+    probe.enabled = False
+    _native.chamfer_forward = probe.orig
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    losses = [float(x) * 1000 for x in last]
+
+    if rank == 0:
+        out = {
+            "metric": "clouds/sec (train step, bs=32/GPU), AdaPoinTr PCN 2048->16384",
+            "value": round(world * B * args.steps / dt, 3), "unit": "clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
+                                   f"bs={B}/GPU, full train step (BASELINE configs[1])",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "params": sum(p.numel() for p in model.parameters())},
+            "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
+            "roofline": probe.summary(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,2 @@
+from .build import DATASETS, build_dataset_from_cfg  # noqa: F401
+from . import SyntheticPCN  # noqa: F401

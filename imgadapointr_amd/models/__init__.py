@@ -1,0 +1,2 @@
+from .build import MODELS, build_model_from_cfg  # noqa: F401
+from . import AdaPoinTr  # noqa: F401  (registers 'AdaPoinTr')

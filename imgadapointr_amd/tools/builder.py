@@ -1,0 +1,141 @@
+"""Builders used by the runner (interface of tools/builder.py of the reference).
+
+dataset_builder :14, model_builder :33, build_optimizer :37, build_scheduler :64,
+resume_model :90, resume_optimizer :115, save_checkpoint :130, load_model :141.
+Checkpoints keep the reference's dict layout ('base_model', 'optimizer', 'epoch', 'metrics',
+'best_metrics'; 'model' also accepted on load) and key names, so upstream .pth files load.
+"""
+import os
+
+import torch
+import torch.optim as optim
+
+from ..datasets import build_dataset_from_cfg
+from ..models import build_model_from_cfg
+from ..utils.logger import print_log
+from ..utils.misc import build_lambda_bnsche, build_lambda_sche, worker_init_fn
+
+
+def dataset_builder(args, config):
+    dataset = build_dataset_from_cfg(config._base_, config.others)
+    shuffle = config.others.subset == 'train'
+    bs = config.others.bs if shuffle else 1
+    if args.distributed:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=shuffle)
+        # The reference hard-codes batch_size=64 here and ignores the YAML (builder.py:19); the
+        # per-rank batch computed by main.py (total_bs // world_size) is honoured instead.
+        dataloader = torch.utils.data.DataLoader(dataset, batch_size=bs, num_workers=int(args.num_workers),
+                                                 drop_last=shuffle, worker_init_fn=worker_init_fn, sampler=sampler)
+    else:
+        sampler = None
+        dataloader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=shuffle, drop_last=shuffle,
+                                                 num_workers=int(args.num_workers), worker_init_fn=worker_init_fn)
+    return sampler, dataloader
+
+
+def model_builder(config):
+    return build_model_from_cfg(config)
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, 'module') else model
+
+
+def build_optimizer(base_model, config):
+    opti_config = config.optimizer
+    net = _unwrap(base_model)
+    if opti_config.type == 'AdamW':
+        decay, no_decay = [], []
+        for name, param in net.named_parameters():
+            if not param.requires_grad:
+                continue
+            # no weight decay for 1-D parameters (norm scales) and biases (builder.py:40-52)
+            (no_decay if param.dim() == 1 or name.endswith('.bias') else decay).append(param)
+        groups = [{'params': no_decay, 'weight_decay': 0.},
+                  {'params': decay, 'weight_decay': opti_config.kwargs.weight_decay}]
+        return optim.AdamW(groups, **opti_config.kwargs)
+    trainable = [p for p in net.parameters() if p.requires_grad]
+    if opti_config.type == 'Adam':
+        return optim.Adam(trainable, **opti_config.kwargs)
+    if opti_config.type == 'SGD':
+        return optim.SGD(trainable, **opti_config.kwargs)
+    raise NotImplementedError(opti_config.type)
+
+
+def build_scheduler(base_model, optimizer, config, last_epoch=-1):
+    sche_config = config.scheduler
+    if sche_config.type == 'LambdaLR':
+        scheduler = build_lambda_sche(optimizer, sche_config.kwargs, last_epoch=last_epoch)
+    elif sche_config.type == 'StepLR':
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, last_epoch=last_epoch, **sche_config.kwargs)
+    else:
+        raise NotImplementedError(f'scheduler {sche_config.type} is not used by the AdaPoinTr YAMLs')
+    if config.get('bnmscheduler') is not None:
+        bn_cfg = config.bnmscheduler
+        if bn_cfg.type == 'Lambda':
+            scheduler = [scheduler, build_lambda_bnsche(_unwrap(base_model), bn_cfg.kwargs)]
+    return scheduler
+
+
+def _strip_module(sd):
+    return {k.replace('module.', ''): v for k, v in sd.items()}
+
+
+def resume_model(base_model, args, logger=None):
+    ckpt_path = os.path.join(args.experiment_path, 'ckpt-last.pth')
+    if not os.path.exists(ckpt_path):
+        print_log(f'[RESUME INFO] no checkpoint file from path {ckpt_path}...', logger=logger)
+        return 0, 0
+    print_log(f'[RESUME INFO] Loading model weights from {ckpt_path}...', logger=logger)
+    state_dict = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    _unwrap(base_model).load_state_dict(_strip_module(state_dict['base_model']))
+    start_epoch = state_dict['epoch'] + 1
+    best_metrics = state_dict['best_metrics']
+    if not isinstance(best_metrics, dict):
+        best_metrics = best_metrics.state_dict()
+    print_log(f'[RESUME INFO] resume ckpts @ {start_epoch - 1} epoch( best_metrics = {str(best_metrics):s})',
+              logger=logger)
+    return start_epoch, best_metrics
+
+
+def resume_optimizer(optimizer, args, logger=None):
+    ckpt_path = os.path.join(args.experiment_path, 'ckpt-last.pth')
+    if not os.path.exists(ckpt_path):
+        print_log(f'[RESUME INFO] no checkpoint file from path {ckpt_path}...', logger=logger)
+        return 0, 0, 0
+    print_log(f'[RESUME INFO] Loading optimizer from {ckpt_path}...', logger=logger)
+    state_dict = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    optimizer.load_state_dict(state_dict['optimizer'])
+
+
+def save_checkpoint(base_model, optimizer, epoch, metrics, best_metrics, prefix, args, logger=None):
+    if args.local_rank != 0:
+        return
+    path = os.path.join(args.experiment_path, prefix + '.pth')
+    torch.save({
+        'base_model': _unwrap(base_model).state_dict(),
+        'optimizer': optimizer.state_dict(),
+        'epoch': epoch,
+        'metrics': metrics.state_dict() if metrics is not None else dict(),
+        'best_metrics': best_metrics.state_dict() if best_metrics is not None else dict(),
+    }, path)
+    print_log(f'Save checkpoint at {path}', logger=logger)
+
+
+def load_model(base_model, ckpt_path, logger=None):
+    if not os.path.exists(ckpt_path):
+        raise NotImplementedError('no checkpoint file from path %s...' % ckpt_path)
+    print_log(f'Loading weights from {ckpt_path}...', logger=logger)
+    state_dict = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    if state_dict.get('model') is not None:
+        base_ckpt = _strip_module(state_dict['model'])
+    elif state_dict.get('base_model') is not None:
+        base_ckpt = _strip_module(state_dict['base_model'])
+    else:
+        raise RuntimeError('mismatch of ckpt weight')
+    _unwrap(base_model).load_state_dict(base_ckpt)
+    epoch = state_dict.get('epoch', -1)
+    metrics = state_dict.get('metrics', 'No Metrics')
+    if not isinstance(metrics, (dict, str)):
+        metrics = metrics.state_dict()
+    print_log(f'ckpts @ {epoch} epoch( performance = {str(metrics):s})', logger=logger)

@@ -1,0 +1,277 @@
+"""Generates the golden fixtures under tests/golden/ by importing the REFERENCE's own Python.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it does: installs in-process stand-ins for the third-party packages that are
+absent from this image (easydict, timm, torchvision, open3d, ... — empty or trivial), and
+FUNCTIONAL stand-ins, backed by this repository's CPU oracle, for the two native modules the
+reference cannot provide here (`chamfer`, `pointnet2_ops.pointnet2_utils`).  Everything else —
+square_distance / knn_point / index_points, the DGCNN grouper, the attention blocks, the whole
+AdaPoinTr forward, get_loss, the Chamfer reductions, the schedules — is the reference's code,
+executed on CPU.  Only inputs and outputs are written (small .npz / .json); no reference source.
+
+Weights are never stored: both this script and the tests fill a module's state_dict with
+`seeded_state_dict`, a pure function of the key names and shapes.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref as oracle  # noqa: E402
+from golden_util import (demo_partial, seeded_state_dict, synthetic_batch)  # noqa: E402
+
+
+# ------------------------------------------------------------------ stand-ins for absent packages
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_standins():
+    from imgadapointr_amd.utils.config import EasyDict  # attribute dict == easydict.EasyDict
+    _mod("easydict", EasyDict=EasyDict)
+
+    class DropPath(torch.nn.Module):  # drop-path rate is 0 in every AdaPoinTr YAML -> identity
+        def __init__(self, p=0.):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            assert self.p == 0. or not self.training
+            return x
+
+    timm = _mod("timm")
+    timm.models = _mod("timm.models")
+    timm.models.layers = _mod("timm.models.layers", DropPath=DropPath,
+                              trunc_normal_=lambda t, std=1., **kw: torch.nn.init.trunc_normal_(t, std=std, a=-2., b=2.))
+    timm.scheduler = _mod("timm.scheduler", CosineLRScheduler=object)
+    tv = _mod("torchvision")
+    tv.transforms = _mod("torchvision.transforms")
+    tv.models = _mod("torchvision.models")
+    p3 = _mod("pytorch3d")
+    p3.ops = _mod("pytorch3d.ops")
+    p3.ops.points_normals = _mod("pytorch3d.ops.points_normals", estimate_pointcloud_normals=None)
+    for name in ("open3d", "tensorboardX", "wandb", "transforms3d", "h5py", "termcolor", "cv2", "emd",
+                 "gridding", "cubic_feature_sampling", "gridding_distance"):
+        _mod(name)
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.modules["termcolor"].colored = lambda s, *a, **k: s
+
+    # functional stand-ins (the build's CPU restatement)
+    def _t(a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    class _FPS(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xyz, npoint):
+            return _t(oracle.furthest_point_sample(xyz.detach().numpy(), npoint))
+
+        @staticmethod
+        def backward(ctx, g):
+            return None, None
+
+    class _Gather(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, idx):
+            ctx.save_for_backward(idx)
+            ctx.N = feat.size(2)
+            return _t(oracle.gather_forward(feat.detach().numpy(), idx.numpy()))
+
+        @staticmethod
+        def backward(ctx, g):
+            (idx,) = ctx.saved_tensors
+            return _t(oracle.gather_backward(g.contiguous().numpy(), idx.numpy(), ctx.N)), None
+
+    pn = _mod("pointnet2_ops")
+    pn.pointnet2_utils = _mod("pointnet2_ops.pointnet2_utils", furthest_point_sample=_FPS.apply,
+                              gather_operation=_Gather.apply,
+                              # imported by name by SnowFlakeNet_utils.py:3-4 (never called on this path)
+                              ball_query=None, three_nn=None, three_interpolate=None, grouping_operation=None)
+
+    def ch_fwd(a, b):
+        return [_t(x) for x in oracle.chamfer_forward(a.detach().contiguous().numpy(), b.detach().contiguous().numpy())]
+
+    def ch_bwd(a, b, i1, i2, g1, g2):
+        return [_t(x) for x in oracle.chamfer_backward(a.detach().contiguous().numpy(), b.detach().contiguous().numpy(),
+                                                       i1.numpy(), i2.numpy(), g1.contiguous().numpy(),
+                                                       g2.contiguous().numpy())]
+
+    _mod("chamfer", forward=ch_fwd, backward=ch_bwd)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    oracle.build()
+    install_standins()
+    os.chdir(REF)  # the reference resolves `_base_` YAML paths relative to its root
+    sys.path.insert(0, REF)
+    import builtins
+    real_print = builtins.print
+    from utils.config import cfg_from_yaml_file
+    from models import build_model_from_cfg
+    import models.Transformer_utils as TU
+    import models.base_blocks as BB
+    from extensions.chamfer_dist import (ChamferDistanceL1, ChamferDistanceL1_PM, ChamferDistanceL2,
+                                         ChamferDistanceL2_split)
+    from utils import misc
+
+    torch.set_num_threads(8)
+    out = {}
+
+    # (1) pure-torch functional boundary ----------------------------------------------------
+    rng = np.random.default_rng(1)
+    xyz = torch.from_numpy(rng.random((2, 300, 3), dtype=np.float32) - 0.5)
+    new = torch.from_numpy(rng.random((2, 70, 3), dtype=np.float32) - 0.5)
+    sq = TU.square_distance(new, xyz)
+    knn = TU.knn_point(8, xyz, new)
+    pts = torch.from_numpy(rng.standard_normal((2, 300, 5)).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "functional.npz"), xyz=np_(xyz), new_xyz=np_(new),
+                        square_distance=np_(sq), knn_sorted=np.sort(np_(knn), -1).astype(np.int32),
+                        points=np_(pts), index_points=np_(TU.index_points(pts, knn)))
+
+    # (2) DGCNN grouper ----------------------------------------------------------------------
+    builtins.print = lambda *a, **k: None  # the reference prints from constructors / get_loss
+    g = BB.DGCNN_Grouper(k=16)
+    g.load_state_dict(seeded_state_dict(g.state_dict(), "grouper"))
+    g.eval()
+    gx = torch.from_numpy(synthetic_batch(2, 512, 64, seed=2, structured=True)[0])
+    coor, f = g(gx, [128, 64])
+    np.savez_compressed(os.path.join(HERE, "grouper.npz"), x=np_(gx), coor=np_(coor), f=np_(f))
+
+    # (3) attention primitives and block 0 of encoder / decoder -------------------------------
+    dim, heads, k = 48, 6, 8
+    B, N, S = 2, 40, 56
+    q_pos = torch.from_numpy(rng.random((B, S, 3), dtype=np.float32) - 0.5)
+    v_pos = torch.from_numpy(rng.random((B, N, 3), dtype=np.float32) - 0.5)
+    qf = torch.from_numpy(rng.standard_normal((B, S, dim)).astype(np.float32))
+    vf = torch.from_numpy(rng.standard_normal((B, N, dim)).astype(np.float32))
+    blocks = {"q_pos": np_(q_pos), "v_pos": np_(v_pos), "q": np_(qf), "v": np_(vf)}
+
+    attn = TU.Attention(dim, num_heads=heads, qkv_bias=True)
+    attn.load_state_dict(seeded_state_dict(attn.state_dict(), "attn", std=0.2))
+    mask = torch.zeros(S, S)
+    mask[:-16, -16:] = 1.
+    blocks["attn_nomask"] = np_(attn(qf))
+    blocks["attn_mask"] = np_(attn(qf, mask=mask))
+
+    ca = TU.CrossAttention(dim, dim, num_heads=heads, qkv_bias=True)
+    ca.load_state_dict(seeded_state_dict(ca.state_dict(), "cross", std=0.2))
+    blocks["cross"] = np_(ca(qf, vf))
+
+    dga = TU.DynamicGraphAttention(dim, k=k)
+    dga.load_state_dict(seeded_state_dict(dga.state_dict(), "dga", std=0.2))
+    blocks["dga_self"] = np_(dga(qf, q_pos))
+    blocks["dga_cross"] = np_(dga(q=qf, v=vf, q_pos=q_pos, v_pos=v_pos))
+    blocks["dga_denoise"] = np_(dga(qf, q_pos, denoise_length=16))
+
+    enc = BB.SelfAttnBlockApi(dim, heads, mlp_ratio=2., qkv_bias=True, block_style='attn-graph',
+                              combine_style='concat', k=k)
+    enc.load_state_dict(seeded_state_dict(enc.state_dict(), "encblock", std=0.2))
+    blocks["enc_block"] = np_(enc(qf, q_pos, idx=TU.knn_point(k, q_pos, q_pos)))
+
+    dec = BB.CrossAttnBlockApi(dim, heads, mlp_ratio=2., qkv_bias=True,
+                               self_attn_block_style='attn-graph', self_attn_combine_style='concat',
+                               cross_attn_block_style='attn-graph', cross_attn_combine_style='concat', k=k)
+    dec.load_state_dict(seeded_state_dict(dec.state_dict(), "decblock", std=0.2))
+    blocks["dec_block_eval"] = np_(dec(qf, vf, q_pos, v_pos, self_attn_idx=TU.knn_point(k, q_pos, q_pos),
+                                       cross_attn_idx=TU.knn_point(k, v_pos, q_pos)))
+    blocks["dec_block_denoise"] = np_(dec(qf, vf, q_pos, v_pos, self_attn_idx=None,
+                                          cross_attn_idx=TU.knn_point(k, v_pos, q_pos), denoise_length=16))
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **blocks)
+
+    # (4)+(5) full model: eval forward, train forward, get_loss --------------------------------
+    cfg = cfg_from_yaml_file('cfgs/PCN_models/AdaPoinTr.yaml')
+    model = build_model_from_cfg(cfg.model)
+    sd = model.state_dict()
+    meta = {"n_params": int(sum(p.numel() for p in model.parameters())),
+            "state_dict": {k_: list(v.shape) for k_, v in sd.items()}}
+    model.load_state_dict(seeded_state_dict(sd, "adapointr"))
+    model.eval()
+    partial_demo = demo_partial(os.path.join(REF, "demo/samples/02691156/00.pcd"))
+    # The scan lies on a depth-camera lattice: 21 of its 1506 points have their 16th/17th neighbour
+    # at (near-)equal distance, where the reference's unsorted top-k picks by rounding accident
+    # (and its CUDA and CPU paths disagree with each other).  A fixed 1e-3 jitter on the real rows
+    # removes the ties and keeps the shape and the zero padding; see DESIGN.md "kNN ties".
+    jit = np.random.default_rng(11).standard_normal(partial_demo.shape).astype(np.float32) * 1e-3
+    partial_demo = np.where(np.abs(partial_demo).sum(-1, keepdims=True) > 0, partial_demo + jit, partial_demo)
+    partial_syn, gt_syn = synthetic_batch(1, 2048, 16384, seed=5, structured=False)
+    xin = torch.from_numpy(np.concatenate([partial_demo[None], partial_syn], 0))
+    with torch.no_grad():
+        coarse, fine = model(xin)
+    full = {"partial": np_(xin), "eval_coarse": np_(coarse), "eval_fine": np_(fine)}
+
+    model.train()
+    torch.manual_seed(123)  # the only RNG consumer of a train forward is misc.jitter_points
+    ret = model(xin)
+    torch.manual_seed(123)
+    noise = torch.stack([torch.empty(64, 3).normal_(mean=0.0, std=0.01).clamp_(-0.05, 0.05) for _ in range(2)])
+    gt = torch.from_numpy(np.concatenate([synthetic_batch(1, 2048, 16384, seed=6, structured=True)[1], gt_syn], 0))
+    l_den, l_rec = model.get_loss(ret, gt)
+    (l_den + l_rec).backward()
+    no_grad = sorted(n for n, p in model.named_parameters() if p.grad is None)
+    gsq = {n: float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters() if p.grad is not None}
+    full.update(train_noise=np_(noise), gt=np_(gt), pred_coarse=np_(ret[0]), denoised_coarse=np_(ret[1]),
+                denoised_fine=np_(ret[2]), pred_fine_head=np_(ret[3][:, :2048]),
+                loss_denoised=np.float64(l_den.item()), loss_recon=np.float64(l_rec.item()))
+    np.savez_compressed(os.path.join(HERE, "adapointr.npz"), **full)
+    meta["no_grad_params"] = no_grad
+    meta["grad_sq_norm_total"] = float(sum(gsq.values()))
+    meta["grad_sq_norm_sample"] = {n: gsq[n] for n in list(gsq)[::37]}
+
+    # (6) Chamfer reductions over given clouds (reference Python on top of the oracle's dist) ---
+    a = torch.from_numpy(synthetic_batch(2, 300, 500, seed=7, structured=True)[0])
+    b = torch.from_numpy(synthetic_batch(2, 300, 500, seed=8, structured=False)[1])
+    red = {"a": np_(a), "b": np_(b),
+           "L1": ChamferDistanceL1()(a, b).item(), "L2": ChamferDistanceL2()(a, b).item(),
+           "L1_PM": ChamferDistanceL1_PM()(a, b).item(),
+           "L2_split": [x.item() for x in ChamferDistanceL2_split()(a, b)],
+           "L1_ignore_zeros_b1": ChamferDistanceL1(ignore_zeros=True)(a[:1], b[:1]).item(),
+           "L2_ignore_zeros_b1": ChamferDistanceL2(ignore_zeros=True)(a[:1], b[:1]).item()}
+    np.savez_compressed(os.path.join(HERE, "chamfer_reductions.npz"), a=red.pop("a"), b=red.pop("b"))
+    meta["chamfer_reductions"] = red
+
+    # (7) schedules ----------------------------------------------------------------------------
+    lin = torch.nn.Linear(4, 4)
+    bnm = torch.nn.Sequential(lin, torch.nn.BatchNorm1d(4))
+    opt = torch.optim.AdamW(bnm.parameters(), lr=1e-4)
+    sch = misc.build_lambda_sche(opt, cfg.scheduler.kwargs)
+    lrs = []
+    for _ in range(60):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    bns = misc.build_lambda_bnsche(bnm, cfg.bnmscheduler.kwargs)
+    meta["lr_first60"] = lrs
+    meta["bn_momentum_epochs"] = {str(e): bns.get_momentum(e) for e in (0, 1, 21, 42, 100, 300, 599)}
+    cyc = BB.CycleLR(5, 1.0, 0.01, 0.995)
+    meta["cycle_lr_5_599"] = [float(cyc.get_lr(e)) for e in range(5, 600)]
+
+    builtins.print = real_print
+    with open(os.path.join(HERE, "meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    for fn in sorted(os.listdir(HERE)):
+        p = os.path.join(HERE, fn)
+        print(f"{fn:32s} {os.path.getsize(p):9d} B  sha1 {hashlib.sha1(open(p, 'rb').read()).hexdigest()[:12]}")
+
+
+if __name__ == "__main__":
+    main()
