@@ -101,6 +101,7 @@ def cpu_baseline(cfg, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)  # the GPU box's CPU share for one GPU; more threads only oversubscribe
     torch.set_num_threads(cores)
     oracle.set_num_threads(cores)
     _native.set_backend_for_testing(OracleBackend())
@@ -113,13 +114,16 @@ def cpu_baseline(cfg, budget_s=20.0):
         B = 2
         partial = torch.rand(B, N_PARTIAL, 3) - 0.5
         gt = torch.rand(B, N_GT, 3) - 0.5
+        tw = time.time()
         step(partial, gt)  # warm-up
+        tw = time.time() - tw
+        max_steps = max(1, min(12, int(budget_s / max(tw, 1e-3))))
         t0 = time.time()
         n = 0
-        while True:
+        while n < max_steps:
             step(partial, gt)
             n += 1
-            if time.time() - t0 > budget_s or n >= 12:
+            if time.time() - t0 > budget_s:
                 break
         dt = time.time() - t0
     finally:
@@ -139,6 +143,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,9 +180,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note("model built; warm-up")
+    for i in range(args.warmup):
         step(partial, gt)
+        if i == 0:
+            torch.cuda.synchronize()
+            note("first step done")
     barrier()
+    note("timed region")
     probe.enabled = True
     t0 = time.perf_counter()
     last = None
@@ -185,6 +199,7 @@ def main():
         last = step(partial, gt)
     barrier()
     dt = time.perf_counter() - t0
+    note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     probe.enabled = False
     _native.chamfer_forward = probe.orig
 

@@ -24,6 +24,10 @@ def seeded_state_dict(sd, tag, std=0.02):
             t = 0.05 * n
         elif ref.dim() == 1 and key.endswith("weight"):
             t = 1.0 + 0.1 * n
+        elif "query_ranking" in key:
+            # wide scores: the top-512-of-768 query selection (argsort) must not hinge on 1e-7 noise
+            # (std 0.3 gives pre-sigmoid scores of order 1: spread out, not saturated)
+            t = (0.3 if key.endswith("weight") else 0.1) * n
         else:
             t = std * n
         out[key] = t.to(ref.dtype)

@@ -170,3 +170,21 @@ def check_train_forward_and_loss(device, tol=2e-4):
     for n, v in mt["grad_sq_norm_sample"].items():
         assert abs(gsq[n] - v) <= 5e-3 * max(v, 1e-12) + 1e-12, (n, gsq[n], v)
     return l_den.item(), l_rec.item()
+
+
+def describe_eval_forward(device):
+    """Diagnostics for the eval forward: per-sample max deviation, row-order agreement."""
+    g = load("adapointr.npz")
+    model, _ = build_adapointr(device)
+    model.eval()
+    with torch.no_grad():
+        coarse, fine = model(t(g["partial"], device))
+    c, w = coarse.cpu().numpy(), g["eval_coarse"]
+    out = []
+    for b in range(c.shape[0]):
+        d = ((c[b][:, None, :] - w[b][None, :, :]) ** 2).sum(-1)
+        out.append(dict(sample=b, same_index_max=float(np.abs(c[b] - w[b]).max()),
+                        best_match_max=float(np.sqrt(d.min(1)).max()),
+                        rows_out_of_order=int((d.argmin(1) != np.arange(c.shape[1])).sum()),
+                        fine_max=float(np.abs(fine[b].cpu().numpy() - g["eval_fine"][b]).max())))
+    return out
