@@ -1,0 +1,114 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the data-parallel path: FlatDDP gradient
+averaging, unused-parameter handling, and a two-rank AdaPoinTr train step on the oracle backend."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.unused = nn.Linear(3, 3)      # never receives a gradient
+        self.bn = nn.BatchNorm1d(16)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.bn(self.a(x))))
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _toy_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from imgadapointr_amd.utils.flat_ddp import FlatDDP
+    _init(rank, world, port)
+    torch.manual_seed(100 + rank)            # different initial weights: FlatDDP must broadcast rank 0's
+    net = Toy()
+    ddp = FlatDDP(net, bucket_mb=0.0005)     # tiny buckets -> several collectives
+    opt = torch.optim.SGD([p for p in net.parameters()], lr=0.1)
+    torch.manual_seed(7)
+    data = torch.randn(3, 2 * 6, 8)          # 3 steps, global batch 12
+    ddp.zero_grad()
+    for step in range(3):
+        x = data[step, rank * 6:(rank + 1) * 6]
+        loss = ddp(x).pow(2).mean()
+        loss.backward()
+        ddp.finalize()
+        assert net.unused.weight.grad is None and net.unused.bias.grad is None
+        opt.step()
+        ddp.zero_grad()
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in net.state_dict().items()}, out)
+    sd = [None, None]
+    dist.all_gather_object(sd, {k: v for k, v in net.state_dict().items() if "running" not in k and "num_b" not in k})
+    for k in sd[0]:
+        assert torch.equal(sd[0][k], sd[1][k]), k   # ranks stay in lock-step
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_matches_single_process(tmp_path):
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_toy_worker, args=(2, 29611, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process on the full batch, BatchNorm statistics per half (what unsynchronised BN sees)
+    torch.manual_seed(100)
+    net = Toy()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    torch.manual_seed(7)
+    data = torch.randn(3, 12, 8)
+    for step in range(3):
+        opt.zero_grad()
+        loss = 0.5 * (net(data[step, :6]).pow(2).mean() + net(data[step, 6:]).pow(2).mean())
+        loss.backward()
+        opt.step()
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k or k.startswith("unused"):
+            continue
+        assert torch.allclose(got[k], v, rtol=1e-5, atol=1e-6), k
+
+
+def _model_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleBackend
+    from imgadapointr_amd import _native
+    from imgadapointr_amd.tools import builder
+    from imgadapointr_amd.tools.runner import TrainStep
+    from imgadapointr_amd.utils.flat_ddp import FlatDDP
+    import parity_checks as pc
+    _init(rank, world, port)
+    _native.set_backend_for_testing(OracleBackend())
+    model, cfg = pc.build_adapointr("cpu")
+    model.train()
+    ddp = FlatDDP(model)
+    step = TrainStep(ddp, builder.build_optimizer(ddp, cfg))
+    torch.manual_seed(rank)
+    partial, gt = torch.rand(1, 2048, 3) - 0.5, torch.rand(1, 16384, 3) - 0.5
+    l1, l2 = step(partial, gt)
+    l1, l2 = step(partial, gt)               # second step exercises the overlapped (hook) path
+    assert torch.isfinite(l1) and torch.isfinite(l2)
+    unused = [n for n, p in model.named_parameters() if p.grad is None]
+    assert len(unused) == 8                  # encoder.norm.* and query_ranking.* 
+    w = model.reduce_map.weight.detach().clone()
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    assert torch.equal(ws[0], ws[1])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_adapointr_train_step(tmp_path):
+    mp.spawn(_model_worker, args=(2, 29612, str(tmp_path / "x")), nprocs=2, join=True)

@@ -1,0 +1,105 @@
+"""run_net / validate / checkpoint round trip on CPU (oracle backend) with a tiny AdaPoinTr."""
+import argparse
+import os
+
+import pytest
+import torch
+
+from oracle_backend import OracleBackend
+
+
+def tiny_config():
+    from imgadapointr_amd.utils.config import EasyDict
+    blk = dict(embed_dim=48, num_heads=6, k=8, n_group=2, mlp_ratio=2.)
+    ds = dict(NAME='SyntheticPCN', N_POINTS=512, N_PARTIAL=256, LENGTH=4)
+    return EasyDict(
+        optimizer=dict(type='AdamW', kwargs=dict(lr=1e-3, weight_decay=5e-4)),
+        scheduler=dict(type='LambdaLR', kwargs=dict(decay_step=21, lr_decay=0.9, lowest_decay=0.02)),
+        bnmscheduler=dict(type='Lambda', kwargs=dict(decay_step=21, bn_decay=0.5, bn_momentum=0.9, lowest_decay=0.01)),
+        dataset=dict(train=dict(_base_=dict(ds), others=dict(subset='train', bs=2)),
+                     val=dict(_base_=dict(ds, LENGTH=2), others=dict(subset='val')),
+                     test=dict(_base_=dict(ds, LENGTH=2), others=dict(subset='test'))),
+        model=dict(NAME='AdaPoinTr', num_query=32, num_points=512, center_num=[64, 32], global_feature_dim=64,
+                   encoder_type='graph', decoder_type='fc',
+                   encoder_config=dict(blk, depth=2, block_style_list=['attn-graph', 'attn'], combine_style='concat'),
+                   decoder_config=dict(blk, depth=2, self_attn_block_style_list=['attn-graph', 'attn'],
+                                       self_attn_combine_style='concat',
+                                       cross_attn_block_style_list=['attn-graph', 'attn'],
+                                       cross_attn_combine_style='concat')),
+        total_bs=2, step_per_update=1, max_epoch=1, consider_metric='CDL1')
+
+
+@pytest.fixture()
+def oracle_backend(ref):
+    from imgadapointr_amd import _native
+    _native.set_backend_for_testing(OracleBackend())
+    yield
+    _native.set_backend_for_testing(None)
+
+
+def make_args(tmp_path, **kw):
+    a = argparse.Namespace(distributed=False, world_size=1, local_rank=0, use_gpu=False, num_workers=0,
+                           resume=False, start_ckpts=None, ckpts=None, val_freq=1, sync_bn=False, log_every=1,
+                           experiment_path=str(tmp_path), log_name='tiny', test=False)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_run_net_validate_and_resume(tmp_path, oracle_backend):
+    from imgadapointr_amd.tools import builder, runner
+    from imgadapointr_amd.utils.metrics import Metrics
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    args = make_args(tmp_path)
+    best = runner.run_net(args, cfg)                     # epochs 0 and 1, validation + checkpoints
+    assert isinstance(best, Metrics)
+    for name in ('ckpt-best.pth', 'ckpt-last.pth', 'ckpt-epoch-000.pth', 'ckpt-epoch-001.pth'):
+        assert os.path.exists(tmp_path / name), name
+    ck = torch.load(tmp_path / 'ckpt-last.pth', weights_only=False)
+    assert set(ck) == {'base_model', 'optimizer', 'epoch', 'metrics', 'best_metrics'}   # builder.py:132-138
+    assert ck['epoch'] == 1 and set(ck['metrics']) == {'F-Score', 'CDL1', 'CDL2', 'EMDistance'}
+    assert all(k.startswith(('base_model.', 'decode_head.', 'increase_dim.', 'reduce_map.')) for k in ck['base_model'])
+
+    # resume picks up model, optimizer and epoch
+    model = builder.model_builder(cfg.model)
+    start_epoch, best_metrics = builder.resume_model(model, make_args(tmp_path, resume=True))
+    assert start_epoch == 2 and 'CDL1' in best_metrics
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ck['base_model'][k])
+    # load_model accepts both 'base_model' and 'model' keys and strips 'module.' (builder.py:149-154)
+    torch.save({'model': {'module.' + k: v for k, v in ck['base_model'].items()}}, tmp_path / 'alt.pth')
+    builder.load_model(builder.model_builder(cfg.model), str(tmp_path / 'alt.pth'))
+
+    # test_net on the saved checkpoint
+    m = runner.test_net(make_args(tmp_path, ckpts=str(tmp_path / 'ckpt-best.pth'), test=True), cfg)
+    assert m.state_dict()['CDL1'] > 0
+
+
+def test_metrics_f_score_and_cd(oracle_backend):
+    from imgadapointr_amd.utils.metrics import Metrics
+    torch.manual_seed(1)
+    gt = torch.rand(2, 300, 3)
+    vals = Metrics.get(gt.clone(), gt)
+    assert abs(vals[0].item() - 1.0) < 1e-6 and vals[1].item() == 0 and vals[2].item() == 0 and vals[3].item() == 0
+    far = gt + 10.0
+    assert Metrics.get(far, gt)[0].item() == 0.0
+    half = gt.clone()
+    half[:, :150] += 10.0                     # half the predicted points are far away
+    f = Metrics.get(half, gt)[0].item()       # precision 0.5, recall 0.5 -> F = 0.5
+    assert abs(f - 0.5) < 1e-6
+    a, b = Metrics('CDL1', {'CDL1': 5.0}), Metrics('CDL1', {'CDL1': 6.0})
+    assert a.better_than(b) and not b.better_than(a) and a.better_than(None)
+    c, d = Metrics('F-Score', {'F-Score': 0.9}), Metrics('F-Score', {'F-Score': 0.8})
+    assert c.better_than(d)
+
+
+def test_parser_paths(tmp_path, monkeypatch):
+    from imgadapointr_amd.utils import parser
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv('LOCAL_RANK', raising=False)
+    args = parser.get_args(['--config', 'cfgs/PCN_models/AdaPoinTr.yaml', '--exp_name', 'x', '--mode', 'hard'])
+    assert args.experiment_path == os.path.join('./experiments', 'AdaPoinTr', 'PCN_models', 'x_hard')
+    assert args.tfboard_path == os.path.join('./experiments', 'AdaPoinTr', 'PCN_models', 'TFBoard', 'x_hard')
+    assert args.log_name == 'AdaPoinTr' and os.path.isdir(args.experiment_path)
+    with pytest.raises(ValueError):
+        parser.get_args(['--test', '--resume'])
