@@ -20,6 +20,7 @@
 // Arithmetic (bit-exact with oracle/ptops_ref.c sqdist_direct): d = fma(dz,dz,fma(dy,dy,dx*dx)),
 // d* = candidate - query.  Compiled with -ffp-contract=off; all fmas are explicit.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ptops_common.h"
 
@@ -55,7 +56,16 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float cx, 
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-template <int Q>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two queries per instruction: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 (same IEEE operations,
+// so the result is bit-identical to sqdist()).
+__device__ __forceinline__ f32x2 sqdist2(f32x2 qx, f32x2 qy, f32x2 qz, float cx, float cy, float cz) {
+  const f32x2 dx = f32x2{cx, cx} - qx, dy = f32x2{cy, cy} - qy, dz = f32x2{cz, cz} - qz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+template <int Q, bool PK>
 __global__ __launch_bounds__(kTPB) void chamfer_nn_kernel(Args a) {
   const int bid = blockIdx.x;
   const bool second = bid >= a.d[1].first_block;
@@ -106,14 +116,29 @@ __global__ __launch_bounds__(kTPB) void chamfer_nn_kernel(Args a) {
     for (int g = 0; g < kCH / 4; ++g) {
       // Uniform address -> s_load_dwordx4/x8: the candidates live in SGPRs.
       const Cand4 cc = cp[g];
+      if constexpr (PK && (Q % 2 == 0)) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        float d0 = sqdist(qx[i], qy[i], qz[i], cc.v[0], cc.v[1], cc.v[2]);
-        float d1 = sqdist(qx[i], qy[i], qz[i], cc.v[3], cc.v[4], cc.v[5]);
-        float d2 = sqdist(qx[i], qy[i], qz[i], cc.v[6], cc.v[7], cc.v[8]);
-        float d3 = sqdist(qx[i], qy[i], qz[i], cc.v[9], cc.v[10], cc.v[11]);
-        m[i] = __builtin_fminf(__builtin_fminf(m[i], d0), d1);
-        m[i] = __builtin_fminf(__builtin_fminf(m[i], d2), d3);
+        for (int i = 0; i < Q; i += 2) {
+          const f32x2 x2{qx[i], qx[i + 1]}, y2{qy[i], qy[i + 1]}, z2{qz[i], qz[i + 1]};
+          const f32x2 d0 = sqdist2(x2, y2, z2, cc.v[0], cc.v[1], cc.v[2]);
+          const f32x2 d1 = sqdist2(x2, y2, z2, cc.v[3], cc.v[4], cc.v[5]);
+          const f32x2 d2 = sqdist2(x2, y2, z2, cc.v[6], cc.v[7], cc.v[8]);
+          const f32x2 d3 = sqdist2(x2, y2, z2, cc.v[9], cc.v[10], cc.v[11]);
+          m[i] = __builtin_fminf(__builtin_fminf(m[i], d0.x), d1.x);
+          m[i] = __builtin_fminf(__builtin_fminf(m[i], d2.x), d3.x);
+          m[i + 1] = __builtin_fminf(__builtin_fminf(m[i + 1], d0.y), d1.y);
+          m[i + 1] = __builtin_fminf(__builtin_fminf(m[i + 1], d2.y), d3.y);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+          float d0 = sqdist(qx[i], qy[i], qz[i], cc.v[0], cc.v[1], cc.v[2]);
+          float d1 = sqdist(qx[i], qy[i], qz[i], cc.v[3], cc.v[4], cc.v[5]);
+          float d2 = sqdist(qx[i], qy[i], qz[i], cc.v[6], cc.v[7], cc.v[8]);
+          float d3 = sqdist(qx[i], qy[i], qz[i], cc.v[9], cc.v[10], cc.v[11]);
+          m[i] = __builtin_fminf(__builtin_fminf(m[i], d0), d1);
+          m[i] = __builtin_fminf(__builtin_fminf(m[i], d2), d3);
+        }
       }
     }
 #pragma unroll
@@ -209,17 +234,34 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 
 struct Plan {
   int Q;
+  bool pk;
   int qtiles[2], splits[2], cps[2];
   bool need_ws;
 };
 
+#ifdef PTOPS_TUNING  // benchmarks/chamfer_tune.py: `make clean && make TUNING=1`
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+inline int env_int(const char*, int dflt) { return dflt; }
+#endif
+
 // Pure function of (B, n, m): decides the query tiling and candidate splits.
+// Measured on MI355X (profiles/round1/chamfer_tune.log): 4 queries per lane win when both clouds
+// are large, 2 otherwise; the packed-math body (v_pk_*_f32, same flops per cycle, fewer issued
+// instructions) is 2-3 % faster than the scalar body at every Q.
 Plan make_plan(int B, int n, int m) {
   Plan p;
-  const long long big = (long long)B * (n > m ? n : m);
-  p.Q = big >= 256LL * 1024 ? 4 : (big >= 64LL * 1024 ? 2 : 1);
+  const int small = n < m ? n : m;
+  p.Q = small >= 4096 ? 4 : ((long long)B * (n > m ? n : m) >= 16 * 1024 ? 2 : 1);
+  p.Q = env_int("PTOPS_TUNE_Q", p.Q);
+  p.pk = env_int("PTOPS_TUNE_PK", 1) != 0;
+  const int force_split = env_int("PTOPS_TUNE_SPLITS", 0);
+  const int target_mult = env_int("PTOPS_TUNE_TARGET", 8);
   const int nq[2] = {n, m}, nc[2] = {m, n};
-  const int target_blocks = 8 * ptops::kNumCU;  // ~8 workgroups (32 waves) per CU
+  const int target_blocks = target_mult * ptops::kNumCU;  // ~8 workgroups (32 waves) per CU
   p.need_ws = false;
   for (int d = 0; d < 2; ++d) {
     p.qtiles[d] = ptops::ceil_div(nq[d], kTPB * p.Q);
@@ -229,6 +271,7 @@ Plan make_plan(int B, int n, int m) {
     const int max_s = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 128 candidates per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
+    if (force_split > 0) s = force_split > max_s ? max_s : force_split;
     int cps = ptops::ceil_div(chunks, (int)s) * kCH;
     s = ptops::ceil_div(nc[d], cps);  // drop empty splits
     p.splits[d] = (int)s;
@@ -280,10 +323,14 @@ PTOPS_API int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B,
   const long long blocks = blocks0 + (long long)B * p.qtiles[1] * p.splits[1];
   PTOPS_REQUIRE(blocks < (1LL << 31), "chamfer_forward: grid too large");
   dim3 grid((unsigned)blocks), block(kTPB);
-  switch (p.Q) {
-    case 4: hipLaunchKernelGGL(chamfer_nn_kernel<4>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(chamfer_nn_kernel<2>, grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL(chamfer_nn_kernel<1>, grid, block, 0, stream, a); break;
+  switch (p.Q * 2 + (p.pk ? 1 : 0)) {
+    case 17: hipLaunchKernelGGL((chamfer_nn_kernel<8, true>), grid, block, 0, stream, a); break;
+    case 16: hipLaunchKernelGGL((chamfer_nn_kernel<8, false>), grid, block, 0, stream, a); break;
+    case 9: hipLaunchKernelGGL((chamfer_nn_kernel<4, true>), grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((chamfer_nn_kernel<4, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((chamfer_nn_kernel<2, true>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((chamfer_nn_kernel<2, false>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((chamfer_nn_kernel<1, false>), grid, block, 0, stream, a); break;
   }
   int rc = ptops::check_launch("chamfer_nn_kernel");
   if (rc != PTOPS_OK) return rc;
