@@ -34,6 +34,7 @@ from imgadapointr_amd.tools import builder  # noqa: E402
 from imgadapointr_amd.tools.runner import TrainStep  # noqa: E402
 from imgadapointr_amd.utils.config import cfg_from_yaml_file  # noqa: E402
 from imgadapointr_amd.utils.flat_ddp import FlatDDP  # noqa: E402
+from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
@@ -141,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="clouds per GPU (the metric is quoted at 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the GEMM kernel choice to the library default")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -158,6 +160,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
     _native.load()
+    gemm = "library default" if args.no_gemm_tuning else enable_tuned_gemm()
 
     cfg = load_cfg()
     torch.manual_seed(0)                     # identical weights on every rank
@@ -218,7 +221,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
                                    f"bs={B}/GPU, full train step (BASELINE configs[1])",
-                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "gemm_selection": gemm,
                        "params": sum(p.numel() for p in model.parameters())},
             "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
             "roofline": probe.summary(),

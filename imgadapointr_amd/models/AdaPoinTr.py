@@ -19,7 +19,7 @@ from ..pointnet2_ops import pointnet2_utils
 from .base_blocks import (DGCNN_Grouper, Fold, PointTransformerDecoderEntry, PointTransformerEncoderEntry,
                           SimpleRebuildFCLayer, trunc_normal_)
 from .build import MODELS
-from .Transformer_utils import index_points, knn_idx
+from .Transformer_utils import index_points, knn_idx, linear_on_broadcast_concat
 
 
 class PCTransformer(nn.Module):
@@ -110,8 +110,10 @@ class PCTransformer(nn.Module):
         else:
             denoise_length = 0
 
-        q = self.mlp_query(torch.cat(
-            [global_feature.unsqueeze(1).expand(-1, coarse.size(1), -1), coarse], dim=-1))
+        # mlp_query(cat([global_feature broadcast, coarse])) with its first Linear split
+        q = linear_on_broadcast_concat(self.mlp_query[0], global_feature, coarse)
+        for layer in list(self.mlp_query)[1:]:
+            q = layer(q)
         if self.training:
             q = self.decoder(q=q, v=mem, q_pos=coarse, v_pos=coor, denoise_length=denoise_length)
         else:
@@ -166,15 +168,14 @@ class AdaPoinTr(nn.Module):
 
         global_feature = self.increase_dim(q.transpose(1, 2)).transpose(1, 2)   # [B,M,1024]
         global_feature = torch.max(global_feature, dim=1)[0]
-        rebuild_feature = torch.cat(
-            [global_feature.unsqueeze(-2).expand(-1, M, -1), q, coarse_point_cloud], dim=-1)
+        # reduce_map(cat([global_feature broadcast (1024), q (C), coarse (3)])), AdaPoinTr.py:226-239
+        rebuild_feature = linear_on_broadcast_concat(
+            self.reduce_map, global_feature, torch.cat([q, coarse_point_cloud], dim=-1))
 
         if self.decoder_type == 'fold':
-            rebuild_feature = self.reduce_map(rebuild_feature.reshape(B * M, -1))
-            relative_xyz = self.decode_head(rebuild_feature).reshape(B, M, 3, -1)
+            relative_xyz = self.decode_head(rebuild_feature.reshape(B * M, -1)).reshape(B, M, 3, -1)
             rebuild_points = (relative_xyz + coarse_point_cloud.unsqueeze(-1)).transpose(2, 3)
         else:
-            rebuild_feature = self.reduce_map(rebuild_feature)
             relative_xyz = self.decode_head(rebuild_feature)                     # [B,M,S,3]
             rebuild_points = relative_xyz + coarse_point_cloud.unsqueeze(-2)
 

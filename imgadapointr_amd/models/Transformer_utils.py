@@ -26,6 +26,21 @@ FUSED_GRAPH_ATTENTION = True
 USE_SDPA = True
 
 
+# Linear layers whose input is cat([per-cloud vector broadcast over tokens, per-token features]):
+# True evaluates W.[g; x] as W_g.g (once per cloud) + W_x.x (per token) — exact in real arithmetic,
+# removes the broadcast/concat tensor and the K=1024 part of a [B*M, 1027..1411] GEMM.
+SPLIT_BROADCAST_LINEAR = True
+
+
+def linear_on_broadcast_concat(lin, g, x):
+    """lin(cat([g.unsqueeze(1).expand(-1, M, -1), x], -1)) for g [B,G], x [B,M,X], lin: Linear(G+X, O)."""
+    if not SPLIT_BROADCAST_LINEAR:
+        return lin(torch.cat([g.unsqueeze(1).expand(-1, x.size(1), -1), x], dim=-1))
+    G = g.size(-1)
+    per_cloud = F.linear(g, lin.weight[:, :G], lin.bias)        # [B,O]
+    return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
+
+
 # ------------------------------------------------------------------------------ functional
 def knn_idx(nsample, xyz, new_xyz):
     """int32 [B,S,nsample] neighbour indices, ordered by (distance, index).  No gradient."""

@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import _native
 from ..pointnet2_ops import pointnet2_utils
 from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerScale, Mlp,
-                                knn_idx)
+                                knn_idx, linear_on_broadcast_concat)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
 
@@ -466,9 +466,10 @@ class SimpleRebuildFCLayer(nn.Module):
     def forward(self, rec_feature):
         batch_size = rec_feature.size(0)
         g_feature = rec_feature.max(1)[0]
-        patch_feature = torch.cat(
-            [g_feature.unsqueeze(1).expand(-1, rec_feature.size(1), -1), rec_feature], dim=-1)
-        rebuild_pc = self.layer(patch_feature).reshape(batch_size, -1, self.step, 3)
+        # self.layer(cat([g_feature broadcast, rec_feature])) with the first Linear split
+        mlp = self.layer
+        h = linear_on_broadcast_concat(mlp.fc1, g_feature, rec_feature)
+        rebuild_pc = mlp.drop(mlp.fc2(mlp.drop(mlp.act(h)))).reshape(batch_size, -1, self.step, 3)
         assert rebuild_pc.size(1) == rec_feature.size(1)
         return rebuild_pc
 
