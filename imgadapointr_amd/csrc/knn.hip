@@ -23,7 +23,8 @@ namespace {
 
 constexpr int kTPB = 256;
 constexpr int kWaves = kTPB / 64;
-constexpr int kQPB = 16;      // queries per workgroup
+// Queries per workgroup: 16 amortise the LDS staging of a tile when there are many queries; with few
+// queries (the 64-seed denoise search over 16384 points) 4 — one per wave — fill the chip instead.
 constexpr int kMaxK = 64;
 
 __device__ __forceinline__ float wave_min_f32(float v) {
@@ -48,8 +49,8 @@ __device__ __forceinline__ float sumsq3(float x, float y, float z) {
   return (a + b) + c;
 }
 
-// P = candidates per lane per tile (tile = 64*P candidates).
-template <int P>
+// P = candidates per lane per tile (tile = 64*P candidates); kQPB = queries per workgroup.
+template <int P, int kQPB>
 __global__ __launch_bounds__(kTPB) void knn_kernel(const float* __restrict__ xyz,
                                                    const float* __restrict__ new_xyz, int N, int S,
                                                    int k, int32_t* __restrict__ idx_out) {
@@ -176,10 +177,18 @@ PTOPS_API int ptops_knn(const float* xyz, const float* new_xyz, int B, int N, in
   if (B == 0 || S == 0) return PTOPS_OK;
   PTOPS_REQUIRE(xyz && new_xyz && idx, "knn: null pointer");
   PTOPS_REQUIRE(B <= 65535, "knn: B=%d exceeds grid.y limit", B);
-  dim3 grid(ptops::ceil_div(S, kQPB), B), block(kTPB);
-  if (N <= 256) hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);
-  else if (N <= 512) hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);
-  else if (N <= 1024) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);
-  else hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);
+  const bool few = (long long)B * S < 16384;
+  const int qpb = few ? 4 : 16;
+  dim3 grid(ptops::ceil_div(S, qpb), B), block(kTPB);
+#define PTOPS_KNN_LAUNCH(P)                                                                             \
+  do {                                                                                                  \
+    if (few) hipLaunchKernelGGL((knn_kernel<P, 4>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx); \
+    else hipLaunchKernelGGL((knn_kernel<P, 16>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);    \
+  } while (0)
+  if (N <= 256) PTOPS_KNN_LAUNCH(4);
+  else if (N <= 512) PTOPS_KNN_LAUNCH(8);
+  else if (N <= 1024) PTOPS_KNN_LAUNCH(16);
+  else PTOPS_KNN_LAUNCH(32);
+#undef PTOPS_KNN_LAUNCH
   return ptops::check_launch("knn_kernel");
 }
