@@ -36,3 +36,14 @@ class SyntheticPCN(data.Dataset):
         partial[:n_vis] = vis[rng.permutation(len(vis))[:n_vis]]
         tax = self.taxonomies[idx % len(self.taxonomies)]
         return tax, f'synthetic-{idx:05d}', (torch.from_numpy(partial), torch.from_numpy(gt.astype(np.float32)))
+
+
+@DATASETS.register_module()
+class SyntheticImgPCN(SyntheticPCN):
+    """ImgPCN-shaped items: (partial, gt, img[3,224,224]) — datasets/BasePCNDataset.py:100-102."""
+
+    def __getitem__(self, idx):
+        tax, mid, (partial, gt) = super().__getitem__(idx)
+        rng = np.random.default_rng(self.seed * 7919 + idx)
+        img = torch.from_numpy(rng.random((3, 224, 224), dtype=np.float32))
+        return tax, mid, (partial, gt, img)

@@ -69,7 +69,14 @@ class PCTransformer(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
-    def forward(self, xyz, denoise_noise=None):
+    # Hooks for the fusion trunk (models/pctransformer.py); identity for the point-only model.
+    def fuse_encoder_tokens(self, x, coor, img, cls_vec):
+        return x
+
+    def fuse_decoder_tokens(self, q, coarse, denoise_length, cls_vec):
+        return q
+
+    def forward(self, xyz, denoise_noise=None, img=None, cls_vec=None):
         """xyz [B,N,3] -> (q [B,M,C], coarse [B,M,3], denoise_length).
 
         `denoise_noise` ([B,64,3], optional) replaces the random jitter of the denoise seeds so
@@ -85,6 +92,7 @@ class PCTransformer(nn.Module):
         pe = self.pos_embed(coor)
         x = self.input_proj(f)
         x = self.encoder(x + pe, coor)
+        x = self.fuse_encoder_tokens(x, coor, img, cls_vec)
         global_feature = self.increase_dim(x)
         global_feature = torch.max(global_feature, dim=1)[0]               # [B,1024]
 
@@ -118,6 +126,7 @@ class PCTransformer(nn.Module):
             q = self.decoder(q=q, v=mem, q_pos=coarse, v_pos=coor, denoise_length=denoise_length)
         else:
             q = self.decoder(q=q, v=mem, q_pos=coarse, v_pos=coor)
+        q = self.fuse_decoder_tokens(q, coarse, denoise_length, cls_vec)
         return q, coarse, denoise_length
 
 
@@ -131,7 +140,7 @@ class AdaPoinTr(nn.Module):
         self.decoder_type = config.decoder_type
         assert self.decoder_type in ['fold', 'fc'], f'unexpected decoder_type {self.decoder_type}'
         self.fold_step = 8
-        self.base_model = PCTransformer(config)
+        self.base_model = self.build_trunk(config)
         if self.decoder_type == 'fold':
             self.factor = self.fold_step ** 2
             self.decode_head = Fold(self.trans_dim, step=self.fold_step, hidden_dim=256)
@@ -147,6 +156,12 @@ class AdaPoinTr(nn.Module):
         self.reduce_map = nn.Linear(self.trans_dim + 1027, self.trans_dim)
         self.build_loss_func()
 
+    def build_trunk(self, config):
+        return PCTransformer(config)
+
+    def coarse_loss_weight(self, epoch):
+        return 1.0
+
     def build_loss_func(self):
         self.loss_func = ChamferDistanceL1()
 
@@ -159,11 +174,20 @@ class AdaPoinTr(nn.Module):
         denoised_target = index_points(gt, idx).reshape(gt.size(0), -1, 3)
         assert denoised_target.size(1) == denoised_fine.size(1)
         loss_denoised = self.loss_func(denoised_fine, denoised_target) * 0.5
-        loss_recon = self.loss_func(pred_coarse, gt) + self.loss_func(pred_fine, gt)
+        w = self.coarse_loss_weight(epoch)
+        loss_coarse = self.loss_func(pred_coarse, gt)
+        loss_recon = (loss_coarse if w == 1.0 else loss_coarse * w) + self.loss_func(pred_fine, gt)
         return loss_denoised, loss_recon
 
-    def forward(self, xyz, denoise_noise=None):
-        q, coarse_point_cloud, denoise_length = self.base_model(xyz, denoise_noise=denoise_noise)
+    def forward(self, xyz, *extra, denoise_noise=None):
+        q, coarse_point_cloud, denoise_length = self.run_trunk(xyz, extra, denoise_noise)
+        return self.rebuild(q, coarse_point_cloud, denoise_length)
+
+    def run_trunk(self, xyz, extra, denoise_noise):
+        assert not extra, 'AdaPoinTr takes the partial cloud only'
+        return self.base_model(xyz, denoise_noise=denoise_noise)
+
+    def rebuild(self, q, coarse_point_cloud, denoise_length):
         B, M, C = q.shape
 
         global_feature = self.increase_dim(q.transpose(1, 2)).transpose(1, 2)   # [B,M,1024]

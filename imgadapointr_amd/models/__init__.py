@@ -1,2 +1,3 @@
 from .build import MODELS, build_model_from_cfg  # noqa: F401
 from . import AdaPoinTr  # noqa: F401  (registers 'AdaPoinTr')
+from . import ImgResNetEncAdaPoinTrVariableLoss  # noqa: F401

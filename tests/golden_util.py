@@ -72,3 +72,8 @@ def demo_partial(pcd_path, n=2048):
     out = np.zeros((n, 3), np.float32)
     out[:len(a)] = a
     return out
+
+
+def synthetic_image(B, seed=0):
+    """[B,3,224,224] float32 in [0,1): the value range torchvision's ToTensor produces."""
+    return np.random.default_rng(seed).random((B, 3, 224, 224), dtype=np.float32)

@@ -188,3 +188,48 @@ def describe_eval_forward(device):
                         rows_out_of_order=int((d.argmin(1) != np.arange(c.shape[1])).sum()),
                         fine_max=float(np.abs(fine[b].cpu().numpy() - g["eval_fine"][b]).max())))
     return out
+
+
+def build_img_model(device):
+    from imgadapointr_amd.models import build_model_from_cfg
+    from imgadapointr_amd.utils.config import cfg_from_yaml_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        cfg = cfg_from_yaml_file("cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml")
+    finally:
+        os.chdir(cwd)
+    model = build_model_from_cfg(cfg.model)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), "imgadapointr"))
+    return model.to(device), cfg
+
+
+def check_img_model(device, tol=3e-4):
+    """Image-fused model vs the reference fixture: eval forward, train forward, alpha-weighted loss."""
+    from golden_util import synthetic_batch, synthetic_image
+    g = load("imgadapointr.npz")
+    mt = meta()
+    model, _ = build_img_model(device)
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == mt["img_state_dict"]
+    assert sum(p.numel() for p in model.parameters()) == mt["img_n_params"]
+    np.testing.assert_allclose(model.alpha_loss, g["alpha_loss"], rtol=1e-12)
+    partial = t(synthetic_batch(1, 2048, 16384, seed=21, structured=True)[0], device)
+    img = t(synthetic_image(1, seed=22), device)
+    model.eval()
+    with torch.no_grad():
+        coarse, fine = model(partial, img)
+    d_eval = (maxdiff(coarse.cpu().numpy(), g["eval_coarse"]), maxdiff(fine[:, :4096].cpu().numpy(), g["eval_fine_head"]))
+    assert max(d_eval) < tol, d_eval
+    model.train()
+    ret = model(partial, img, denoise_noise=t(g["train_noise"], device))
+    d_train = (maxdiff(ret[0].detach().cpu().numpy(), g["pred_coarse"]),
+               maxdiff(ret[2][:, :512].detach().cpu().numpy(), g["denoised_fine_head"]))
+    assert max(d_train) < tol, d_train
+    gt = t(synthetic_batch(1, 2048, 16384, seed=23, structured=True)[1], device)
+    l_den, l_rec = model.get_loss(ret, gt, 7)
+    assert abs(l_den.item() - float(g["loss_denoised"])) * 1000 < 1e-3
+    assert abs(l_rec.item() - float(g["loss_recon"])) * 1000 < 1e-3
+    # the reference raises IndexError from epoch 595 on; the table is clamped here
+    assert model.coarse_loss_weight(600) == model.alpha_loss[-1]
+    return d_eval, d_train

@@ -36,6 +36,10 @@ def test_train_forward_loss_and_grads_match_reference():
     pc.check_train_forward_and_loss("cpu")
 
 
+def test_image_fused_model_matches_reference():
+    pc.check_img_model("cpu")
+
+
 def test_state_dict_contract():
     mt = pc.meta()
     model, _ = pc.build_adapointr("cpu")

@@ -35,6 +35,10 @@ def test_train_forward_loss_and_grads_match_reference():
     print(pc.check_train_forward_and_loss("cuda"))
 
 
+def test_image_fused_model_matches_reference():
+    print(pc.check_img_model("cuda"))
+
+
 def test_kernels_run_on_the_current_stream():
     """A side stream must see its own work ordered: results equal the default-stream results."""
     from imgadapointr_amd import _native
