@@ -46,6 +46,8 @@ def _declare(lib):
         "ptops_edge_group_backward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
         "ptops_gather_max_forward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
         "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_emd_forward": (c_int, [P, P, c_int, c_int, c_int] + [P] * 12 + [ctypes.c_float, c_int, P]),
+        "ptops_emd_backward": (c_int, [P] * 5 + [c_int] * 3 + [P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -59,7 +61,7 @@ EXPORTS = (
     "ptops_chamfer_forward", "ptops_chamfer_backward", "ptops_furthest_point_sample",
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
-    "ptops_gather_max_forward", "ptops_gather_max_backward",
+    "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
 )
 
 
@@ -331,3 +333,52 @@ def gather_max_backward(grad_out, arg, N):
         _call("ptops_gather_max_backward", _ptr(grad_out), _ptr(arg), B, int(N), C, S, _ptr(g),
               _stream(grad_out))
     return g
+
+
+def emd_forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
+                unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx, eps, iters):
+    """emd.forward (extensions/emd/emd.cpp:6-22): caller-allocated outputs / scratch, mutated in place."""
+    if _test_backend is not None:
+        return _test_backend.emd_forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid,
+                                         bid_increments, max_increments, unass_idx, unass_cnt, unass_cnt_sum,
+                                         cnt_tmp, max_idx, eps, iters)
+    _check(xyz1, "xyz1", torch.float32, 3)
+    _check(xyz2, "xyz2", torch.float32, 3)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    for t, name, dt, numel in ((dist, "dist", torch.float32, B * n), (assignment, "assignment", torch.int32, B * n),
+                               (price, "price", torch.float32, B * m),
+                               (assignment_inv, "assignment_inv", torch.int32, B * m),
+                               (bid, "bid", torch.int32, B * n), (bid_increments, "bid_increments", torch.float32, B * n),
+                               (max_increments, "max_increments", torch.float32, B * m),
+                               (unass_idx, "unass_idx", torch.int32, B * n), (unass_cnt, "unass_cnt", torch.int32, B),
+                               (unass_cnt_sum, "unass_cnt_sum", torch.int32, B), (cnt_tmp, "cnt_tmp", torch.int32, B),
+                               (max_idx, "max_idx", torch.int32, B * m)):
+        _check(t, name, dt, t.dim())
+        if t.numel() < numel:
+            raise ValueError(f"emd_forward: {name} has {t.numel()} elements, needs {numel}")
+    _same_device(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
+                 unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx)
+    with torch.cuda.device(xyz1.device):
+        _call("ptops_emd_forward", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist), _ptr(assignment), _ptr(price),
+              _ptr(assignment_inv), _ptr(bid), _ptr(bid_increments), _ptr(max_increments), _ptr(unass_idx),
+              _ptr(unass_cnt), _ptr(unass_cnt_sum), _ptr(cnt_tmp), _ptr(max_idx), ctypes.c_float(float(eps)),
+              int(iters), _stream(xyz1))
+    return 1
+
+
+def emd_backward(xyz1, xyz2, gradxyz, graddist, idx):
+    """emd.backward (extensions/emd/emd.cpp:24-27): accumulates into the caller's zeroed gradxyz."""
+    if _test_backend is not None:
+        return _test_backend.emd_backward(xyz1, xyz2, gradxyz, graddist, idx)
+    _check(xyz1, "xyz1", torch.float32, 3)
+    _check(xyz2, "xyz2", torch.float32, 3)
+    _check(gradxyz, "gradxyz", torch.float32, 3)
+    _check(graddist, "graddist", torch.float32, 2)
+    _check(idx, "idx", torch.int32, 2)
+    _same_device(xyz1, xyz2, gradxyz, graddist, idx)
+    B, n, _ = xyz1.shape
+    with torch.cuda.device(xyz1.device):
+        _call("ptops_emd_backward", _ptr(xyz1), _ptr(xyz2), _ptr(gradxyz), _ptr(graddist), _ptr(idx), B, n,
+              xyz2.shape[1], _stream(xyz1))
+    return 1

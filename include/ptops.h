@@ -118,6 +118,27 @@ int ptops_gather_max_forward(const float* p, const int32_t* idx, int B, int N, i
 int ptops_gather_max_backward(const float* grad_out, const int32_t* arg, int B, int N,
                               int C, int S, float* grad_p, void* stream);
 
+/* --------------------------------------------------------------------- EMD --
+ * Replaces emd.forward / emd.backward (extensions/emd/emd.cpp:6-31, kernels
+ * extensions/emd/emd_cuda.cu:23-316).  Same caller-allocates contract as the
+ * reference (extensions/emd/emd_module.py:45-56): every output and scratch array is
+ * passed in — dist [B,n] f32, assignment [B,n] i32 pre-filled with -1, price [B,m] f32
+ * zeros, assignment_inv [B,m] i32 pre-filled with -1, bid [B,n] i32, bid_increments
+ * [B,n] f32, max_increments [B,m] f32 zeros, unass_idx [B*n] i32, unass_cnt /
+ * unass_cnt_sum / cnt_tmp [512] i32, max_idx [B*m] i32.  Requires B <= 512, n == m,
+ * n % 1024 == 0 (emd_cuda.cu:236-249; violations return PTOPS_EINVAL).  Ties, which
+ * the CUDA code resolves by race, resolve by lowest index here (csrc/emd.hip).
+ * backward accumulates 2*graddist*(xyz1 - xyz2[idx]) INTO gradxyz (caller zeroes it). */
+int ptops_emd_forward(const float* xyz1, const float* xyz2, int B, int n, int m,
+                      float* dist, int32_t* assignment, float* price,
+                      int32_t* assignment_inv, int32_t* bid, float* bid_increments,
+                      float* max_increments, int32_t* unass_idx, int32_t* unass_cnt,
+                      int32_t* unass_cnt_sum, int32_t* cnt_tmp, int32_t* max_idx,
+                      float eps, int iters, void* stream);
+int ptops_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz,
+                       const float* graddist, const int32_t* idx, int B, int n, int m,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,28 @@ def gather_max_backward(grad_out, arg, N):
     g = np.empty((B, int(N), C), np.float32)
     lib().ref_gather_max_backward(_fp(grad_out), _ip(arg), B, int(N), C, S, _fp(g))
     return g
+
+
+def emd_forward(xyz1, xyz2, eps, iters):
+    """emdFunction.forward (extensions/emd/emd_module.py:31-60): (dist [B,n], assignment [B,n])."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.zeros((B, n), np.float32)
+    assignment = np.empty((B, n), np.int32)
+    assignment_inv = np.empty((B, m), np.int32)
+    price = np.empty((B, m), np.float32)
+    lib().ref_emd_forward.restype = ctypes.c_int
+    rc = lib().ref_emd_forward(_fp(xyz1), _fp(xyz2), B, n, m, ctypes.c_float(eps), int(iters), _fp(dist),
+                               _ip(assignment), _ip(assignment_inv), _fp(price))
+    if rc != 1:
+        raise ValueError("emd: need n == m, n % 1024 == 0, B <= 512")
+    return dist, assignment
+
+
+def emd_backward(xyz1, xyz2, graddist, assignment):
+    xyz1, xyz2, graddist, assignment = _f32(xyz1), _f32(xyz2), _f32(graddist), _i32(assignment)
+    B, n, _ = xyz1.shape
+    g = np.zeros_like(xyz1)
+    lib().ref_emd_backward(_fp(xyz1), _fp(xyz2), _fp(graddist), _ip(assignment), B, n, _fp(g))
+    return g

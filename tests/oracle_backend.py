@@ -55,3 +55,14 @@ class OracleBackend:
 
     def gather_max_backward(self, grad_out, arg, N):
         return _pt(ref.gather_max_backward(_np(grad_out), _np(arg), N), grad_out)
+
+    def emd_forward(self, xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments,
+                    max_increments, unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx, eps, iters):
+        d, a = ref.emd_forward(_np(xyz1), _np(xyz2), eps, iters)
+        dist.copy_(_pt(d, dist))
+        assignment.copy_(_pt(a, assignment))
+        return 1
+
+    def emd_backward(self, xyz1, xyz2, gradxyz, graddist, idx):
+        gradxyz.add_(_pt(ref.emd_backward(_np(xyz1), _np(xyz2), _np(graddist), _np(idx)), gradxyz))
+        return 1

@@ -173,3 +173,41 @@ def test_gather_max(native, ref, B, N, C, S, k):
 def test_cpu_tensor_is_refused(native):
     with pytest.raises(Exception):
         native.chamfer_forward(torch.rand(1, 8, 3), torch.rand(1, 8, 3))
+
+
+@pytest.mark.parametrize("B,n,eps,iters,kind", [(2, 1024, 0.005, 50, "uniform"), (1, 2048, 0.005, 100, "uniform"),
+                                               (3, 1024, 0.002, 200, "dups"), (1, 4096, 0.005, 20, "uniform")])
+def test_emd_forward_backward(native, ref, B, n, eps, iters, kind):
+    from imgadapointr_amd.extensions.emd.emd_module import emdModule
+    rng = np.random.default_rng(n + iters)
+    a = _cloud(rng, B, n, kind) + 0.5     # the auction assumes coordinates in [0, 1]
+    b = _cloud(rng, B, n, "uniform") + 0.5
+    xa = _t(a).requires_grad_(True)
+    dist, assignment = emdModule()(xa, _t(b), eps, iters)
+    rd, ra = ref.emd_forward(a, b, eps, iters)
+    assert np.array_equal(assignment.cpu().numpy(), ra)
+    assert np.array_equal(dist.detach().cpu().numpy(), rd)
+    w = rng.standard_normal((B, n)).astype(np.float32)
+    (dist * _t(w)).sum().backward()
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), ref.emd_backward(a, b, w, ra), rtol=1e-6, atol=1e-7)
+
+
+def test_emd_rejects_bad_shapes(native):
+    from imgadapointr_amd.extensions.emd.emd_module import emdModule
+    with pytest.raises(Exception):
+        emdModule()(torch.rand(1, 1000, 3, device="cuda"), torch.rand(1, 1000, 3, device="cuda"), 0.005, 10)
+    with pytest.raises(Exception):
+        emdModule()(torch.rand(1, 1024, 3, device="cuda"), torch.rand(1, 2048, 3, device="cuda"), 0.005, 10)
+
+
+def test_metrics_with_emd(native, ref):
+    from imgadapointr_amd.utils.metrics import Metrics
+    rng = np.random.default_rng(5)
+    pred, gt = rng.random((1, 1024, 3), dtype=np.float32), rng.random((1, 1024, 3), dtype=np.float32)
+    vals = [v.item() for v in Metrics.get(_t(pred), _t(gt), require_emd=True)]
+    rd, _ = ref.emd_forward(pred, gt, 0.005, 100)
+    assert abs(vals[3] - float(np.sqrt(rd).mean()) * 1000) < 1e-3
+    assert abs(vals[1] - ref.chamfer_l1(pred, gt) * 1000) < 1e-3
+    d1, d2, _, _ = ref.chamfer_forward(pred, gt)
+    p, r = (np.sqrt(d1) < 0.01).mean(), (np.sqrt(d2) < 0.01).mean()
+    assert abs(vals[0] - (2 * p * r / (p + r) if p + r else 0.0)) < 1e-6
