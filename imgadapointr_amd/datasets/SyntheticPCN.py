@@ -47,3 +47,15 @@ class SyntheticImgPCN(SyntheticPCN):
         rng = np.random.default_rng(self.seed * 7919 + idx)
         img = torch.from_numpy(rng.random((3, 224, 224), dtype=np.float32))
         return tax, mid, (partial, gt, img)
+
+
+@DATASETS.register_module()
+class SyntheticSegImgPCN(SyntheticImgPCN):
+    """SegImgPCN-shaped items: (partial, gt, img, cls_vec[16]) — one-hot over the 16 ShapeNetPart
+    classes, only classes 0/4/8/15 occur (datasets/SegImgPCNDataset.py:5-12 of the reference)."""
+
+    def __getitem__(self, idx):
+        tax, mid, (partial, gt, img) = super().__getitem__(idx)
+        cls_vec = torch.zeros(16)
+        cls_vec[(0, 4, 8, 15)[idx % 4]] = 1.0
+        return tax, mid, (partial, gt, img, cls_vec)

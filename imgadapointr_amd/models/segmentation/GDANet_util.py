@@ -1,0 +1,94 @@
+"""Building blocks of GDANet (interface of models/segmentation/GDANet_util.py of the reference):
+feature-space kNN :5-11, local_operator :14-37, local_operator_withnorm :40-70, GDM :73-150,
+SGCAM :153-212.  The kNN here is in feature space (up to 131 channels), so it stays a dense
+matmul + top-k on PyTorch-ROCm; the clouds are the 512 coarse points, i.e. [B,512,512] matrices.
+"""
+import torch
+from torch import nn
+
+
+def knn(x, k):
+    """x [B,C,N] -> (idx [B,N,k] of the k nearest incl. self, negative squared distances [B,N,N])."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pairwise = -xx - inner - xx.transpose(2, 1)
+    return pairwise.topk(k=k, dim=-1)[1], pairwise
+
+
+def _gather_rows(x_nc, idx):
+    """x_nc [B,N,C], idx [B,N,k] -> [B,N,k,C]."""
+    B, N, C = x_nc.shape
+    k = idx.size(-1)
+    flat = idx.reshape(B, N * k, 1).expand(-1, -1, C)
+    return torch.gather(x_nc, 1, flat).view(B, N, k, C)
+
+
+def local_operator(x, k, device=None):
+    """[B,C,N] -> [B,2C,N,k] = cat(neighbour - centre, neighbour)."""
+    idx, _ = knn(x, k=k)
+    xt = x.transpose(2, 1).contiguous()
+    nbr = _gather_rows(xt, idx)
+    centre = xt.unsqueeze(2)
+    return torch.cat((nbr - centre, nbr), dim=3).permute(0, 3, 1, 2)
+
+
+def local_operator_withnorm(x, norm_plt, k, device=None):
+    """x [B,3,N], norm_plt [B,N,3] (viewed as [B,3,N] like the reference) -> [B,9,N,k]."""
+    B, _, N = x.shape
+    norm_plt = norm_plt.contiguous().view(B, -1, N)      # the reference's raw view, not a transpose
+    idx, _ = knn(x, k=k)
+    xt = x.transpose(2, 1).contiguous()
+    nt = norm_plt.transpose(2, 1).contiguous()
+    nbr = _gather_rows(xt, idx)
+    nbr_norm = _gather_rows(nt, idx)
+    return torch.cat((nbr - xt.unsqueeze(2), nbr, nbr_norm), dim=3).permute(0, 3, 1, 2)
+
+
+def GDM(x, M, device=None):
+    """Geometry-disentangle module: the M sharpest and M gentlest points of x [B,C,N] as [B,M,C]."""
+    k, tau, sigma = 64, 0.2, 2
+    B, C, N = x.shape
+    idx, p = knn(x, k=k)                                  # p = -squared distance
+    mask = torch.sqrt(torch.abs(p)) < tau
+    w = torch.exp(p / (sigma * sigma)) * mask.float()     # [B,N,N]
+    # A = D w with D = diag(1 / column sums of w): row i of w scaled by 1/sum_r w[r,i]
+    A = w / torch.sum(w, dim=1).unsqueeze(-1)
+    nb = idx[:, :, 1:k]                                   # drop the first hit (the point itself)
+    Aij = torch.gather(A, 2, nb)                          # [B,N,k-1]
+    xt = x.transpose(2, 1).contiguous()                   # [B,N,C]
+    n = (Aij.unsqueeze(-1) * _gather_rows(xt, nb)).sum(dim=2)
+    pai = torch.norm(xt - n, dim=-1).pow(2)
+    pais = pai.topk(k=M, dim=-1)[1]
+    paig = (-pai).topk(k=M, dim=-1)[1]
+    xs = torch.gather(xt, 1, pais.unsqueeze(-1).expand(-1, -1, C))
+    xg = torch.gather(xt, 1, paig.unsqueeze(-1).expand(-1, -1, C))
+    return xs, xg
+
+
+class SGCAM(nn.Module):
+    """Sharp-gentle complementary attention: non-local block of x over x_2."""
+
+    def __init__(self, in_channels, inter_channels=None, bn_layer=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.inter_channels = inter_channels or max(in_channels // 2, 1)
+        self.g = nn.Conv1d(self.in_channels, self.inter_channels, kernel_size=1)
+        if bn_layer:
+            self.W = nn.Sequential(nn.Conv1d(self.inter_channels, self.in_channels, kernel_size=1),
+                                   nn.BatchNorm1d(self.in_channels))
+            nn.init.constant_(self.W[1].weight, 0)
+            nn.init.constant_(self.W[1].bias, 0)
+        else:
+            self.W = nn.Conv1d(self.inter_channels, self.in_channels, kernel_size=1)
+            nn.init.constant_(self.W.weight, 0)
+            nn.init.constant_(self.W.bias, 0)
+        self.theta = nn.Conv1d(self.in_channels, self.inter_channels, kernel_size=1)
+        self.phi = nn.Conv1d(self.in_channels, self.inter_channels, kernel_size=1)
+
+    def forward(self, x, x_2):
+        g_x = self.g(x_2).permute(0, 2, 1)
+        theta_x = self.theta(x).permute(0, 2, 1)
+        phi_x = self.phi(x_2)
+        W = torch.matmul(theta_x, phi_x)
+        y = torch.matmul(W / W.size(-1), g_x).permute(0, 2, 1).contiguous()
+        return self.W(y) + x

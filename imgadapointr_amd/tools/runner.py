@@ -81,6 +81,22 @@ class TrainStep:
         return sparse_loss.detach(), dense_loss.detach()
 
 
+def load_frozen_segmentator(base_model, weights_path, logger=None):
+    """GDANet weights are loaded (strict=False, 'module.' stripped) and frozen, tools/runner.py:55-66 of
+    the reference.  The reference fails without the file; here a missing file only logs a warning so
+    that synthetic-data runs work, and the segmentator is frozen either way."""
+    seg = base_model.base_model.segmentator
+    if weights_path and os.path.exists(weights_path):
+        state = torch.load(weights_path, map_location='cpu', weights_only=False)['model']
+        seg.load_state_dict({k.replace('module.', ''): v for k, v in state.items()}, strict=False)
+        print_log(f'Loaded segmentator weights from {weights_path}', logger=logger)
+    else:
+        print_log(f'[WARNING] segmentator weights {weights_path} not found: GDANet stays at its initialisation',
+                  logger=logger)
+    for p in seg.parameters():
+        p.requires_grad = False
+
+
 def wrap_model(base_model, args, logger=None):
     if getattr(args, 'distributed', False):
         if getattr(args, 'sync_bn', False):
@@ -105,6 +121,10 @@ def run_net(args, config, train_writer=None, val_writer=None):
     elif args.start_ckpts is not None:
         builder.load_model(base_model, args.start_ckpts, logger=logger)
 
+    dataset_name = config.dataset.train._base_.NAME
+    if 'SegImgPCN' in dataset_name and hasattr(base_model.base_model, 'segmentator'):
+        load_frozen_segmentator(base_model, getattr(args, 'gdanet_w', None), logger)
+
     base_model = wrap_model(base_model, args, logger)
     optimizer = builder.build_optimizer(base_model, config)
     ChamferDisL1, ChamferDisL2 = ChamferDistanceL1(), ChamferDistanceL2()
@@ -113,7 +133,6 @@ def run_net(args, config, train_writer=None, val_writer=None):
     scheduler = builder.build_scheduler(base_model, optimizer, config, last_epoch=start_epoch - 1)
     step = TrainStep(base_model, optimizer, getattr(config, 'grad_norm_clip', 10),
                      getattr(config, 'step_per_update', 1))
-    dataset_name = config.dataset.train._base_.NAME
     log_every = int(getattr(args, 'log_every', 100))
 
     for epoch in range(start_epoch, config.max_epoch + 1):

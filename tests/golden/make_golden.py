@@ -75,7 +75,14 @@ def install_standins():
     tv.models.__dict__["models"] = tv.models
     p3 = _mod("pytorch3d")
     p3.ops = _mod("pytorch3d.ops")
-    p3.ops.points_normals = _mod("pytorch3d.ops.points_normals", estimate_pointcloud_normals=None)
+    # pytorch3d.ops.points_normals: this repository's restatement of estimate_pointcloud_normals (run on
+    # the oracle backend).  The normals are therefore NOT pinned by pytorch3d (absent here).
+    from imgadapointr_amd import _native as _nat
+    from imgadapointr_amd.models.segmentation.normals import estimate_pointcloud_normals as _epn
+    from oracle_backend import OracleBackend
+    _nat.set_backend_for_testing(OracleBackend())
+    p3.ops.points_normals = _mod("pytorch3d.ops.points_normals", estimate_pointcloud_normals=_epn)
+    p3.ops.__dict__["points_normals"] = p3.ops.points_normals
     for name in ("open3d", "tensorboardX", "wandb", "transforms3d", "h5py", "termcolor", "cv2", "emd",
                  "gridding", "cubic_feature_sampling", "gridding_distance"):
         _mod(name)
@@ -271,6 +278,32 @@ def main():
                         pred_coarse=np_(iret[0]), denoised_fine_head=np_(iret[2][:, :512]),
                         loss_denoised=np.float64(il_den.item()), loss_recon=np.float64(il_rec.item()),
                         alpha_loss=np.asarray(imodel.alpha_loss, dtype=np.float64))
+
+    # (5c) segmentation branch: GDANet alone and the image+segmentation fused model (configs[4]) ---
+    from models.segmentation.GDANet_ptseg import GDANet
+    from pytorch3d.ops import points_normals as pn_mod
+    gda = GDANet(50, device='cpu')
+    gda.load_state_dict(seeded_state_dict(gda.state_dict(), "gdanet", std=0.1))
+    gda.eval()
+    spts = torch.from_numpy(synthetic_batch(1, 512, 512, seed=31, structured=False)[0])
+    snorm = pn_mod.estimate_pointcloud_normals(spts, 30, disambiguate_directions=False)
+    scls = torch.zeros(1, 16)
+    scls[0, 4] = 1.0
+    with torch.no_grad():
+        semb, slogp = gda(spts.transpose(1, 2), snorm, scls)
+    scfg = cfg_from_yaml_file('cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml')
+    smodel = build_model_from_cfg(scfg.model)
+    smodel.base_model.segmentator.device = 'cpu'   # the reference hard-codes device='cuda' (GDANet_ptseg.py:8)
+    ssd = smodel.state_dict()
+    meta["seg_n_params"] = int(sum(p.numel() for p in smodel.parameters()))
+    meta["seg_state_dict"] = {k_: list(v.shape) for k_, v in ssd.items()}
+    smodel.load_state_dict(seeded_state_dict(ssd, "imgsegadapointr"))
+    smodel.eval()
+    with torch.no_grad():
+        scoarse, sfine = smodel(ipartial, iimg, scls)
+    np.savez_compressed(os.path.join(HERE, "segadapointr.npz"), gda_emb_head=np_(semb[:, :, :96]),
+                        gda_logp_head=np_(slogp[:, :96]), normals_head=np_(snorm[:, :96]),
+                        eval_coarse=np_(scoarse), eval_fine_head=np_(sfine[:, :4096]))
 
     # (6) Chamfer reductions over given clouds (reference Python on top of the oracle's dist) ---
     a = torch.from_numpy(synthetic_batch(2, 300, 500, seed=7, structured=True)[0])

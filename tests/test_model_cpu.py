@@ -40,6 +40,10 @@ def test_image_fused_model_matches_reference():
     pc.check_img_model("cpu")
 
 
+def test_segmentation_branch_matches_reference():
+    pc.check_seg_branch("cpu")
+
+
 def test_state_dict_contract():
     mt = pc.meta()
     model, _ = pc.build_adapointr("cpu")

@@ -39,6 +39,10 @@ def test_image_fused_model_matches_reference():
     print(pc.check_img_model("cuda"))
 
 
+def test_segmentation_branch_matches_reference():
+    print(pc.check_seg_branch("cuda"))
+
+
 def test_kernels_run_on_the_current_stream():
     """A side stream must see its own work ordered: results equal the default-stream results."""
     from imgadapointr_amd import _native
