@@ -80,10 +80,20 @@ class ChamferProbe:
         flops = FLOP_PER_PAIR * 2.0 * B * n * m
         achieved = flops / (avg_ms * 1e-3) / 1e12
         alg_bytes = 20.0 * B * (n + m)
+        # HBM traffic and VALU activity of this launch come from separate rocprofv3 --pmc passes of the
+        # same kernel (cannot be collected from inside the timed run); their summary is committed.
+        traffic, pmc = None, {}
+        pmc_file = os.path.join(ROOT, "profiles", "round1", "chamfer_pmc.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                pmc = json.load(fh).get("derived", {})
+            traffic = pmc.get("hbm_traffic_bytes_corrected")
         return {
             "bound": "valu-fp32", "kernel": "chamfer_nn_kernel (16384x16384 nearest-neighbour, both directions)",
             "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/round1/chamfer_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+            "valu_busy_fraction_pmc": pmc.get("valu_busy_fraction"),
             "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
             "hbm": {"achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
