@@ -1,0 +1,117 @@
+"""PCN-family dataset readers on a tiny on-disk fixture tree built by the test itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_pcd(path, pts, binary=False):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
+            f"COUNT 1 1 1\nWIDTH {len(pts)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(pts)}\n")
+    with open(path, "wb") as fh:
+        if binary:
+            fh.write((head + "DATA binary\n").encode())
+            fh.write(pts.astype("<f4").tobytes())
+        else:
+            fh.write((head + "DATA ascii\n").encode())
+            for p in pts:
+                fh.write(("%.8g %.8g %.8g\n" % tuple(p)).encode())
+
+
+@pytest.fixture()
+def tree(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    cats = [{"taxonomy_id": "02691156", "train": ["a1", "a2"], "val": ["a3"], "test": ["a3"]},
+            {"taxonomy_id": "02958343", "train": ["c1"], "val": ["c2"], "test": ["c2"]}]
+    (tmp_path / "PCN.json").write_text(json.dumps(cats))
+    clouds = {}
+    for dc in cats:
+        for subset in ("train", "val", "test"):
+            for s in dc[subset]:
+                gt = rng.random((16384, 3)).astype(np.float32) - 0.5
+                _write_pcd(str(tmp_path / subset / "complete" / dc["taxonomy_id"] / f"{s}.pcd"), gt, binary=True)
+                clouds[(subset, s)] = gt
+                for i in range(8 if subset == "train" else 1):
+                    n = int(rng.integers(700, 3000))
+                    _write_pcd(str(tmp_path / subset / "partial" / dc["taxonomy_id"] / s / f"{i:02d}.pcd"), gt[:n])
+                for v in range(24):
+                    d = tmp_path / subset / "image" / dc["taxonomy_id"] / s
+                    d.mkdir(parents=True, exist_ok=True)
+                    Image.fromarray((rng.random((137, 137, 3)) * 255).astype(np.uint8)).save(d / f"{v:02d}.png")
+    return tmp_path, clouds
+
+
+def _cfg(root, subset, name, with_img=False):
+    from imgadapointr_amd.utils.config import EasyDict
+    c = EasyDict(NAME=name, CATEGORY_FILE_PATH=str(root / "PCN.json"), N_POINTS=16384, N_RENDERINGS=8,
+                 PARTIAL_POINTS_PATH=str(root) + "/%s/partial/%s/%s/%02d.pcd",
+                 COMPLETE_POINTS_PATH=str(root) + "/%s/complete/%s/%s.pcd", CARS=False)
+    if with_img:
+        c.IMG_PATH = str(root) + "/%s/image/%s/%s/%02d.png"
+    return c, EasyDict(subset=subset)
+
+
+def test_pcd_reader_ascii_and_binary(tmp_path):
+    from imgadapointr_amd.utils.io_module import IO
+    pts = (np.random.default_rng(1).random((100, 3)).astype(np.float32) - 0.5)
+    _write_pcd(str(tmp_path / "a.pcd"), pts)
+    _write_pcd(str(tmp_path / "b.pcd"), pts, binary=True)
+    assert np.allclose(IO.get(str(tmp_path / "a.pcd")), pts, atol=1e-7)
+    assert np.array_equal(IO.get(str(tmp_path / "b.pcd")).astype(np.float32), pts)
+    np.save(tmp_path / "c.npy", pts)
+    assert np.array_equal(IO.get(str(tmp_path / "c.npy")), pts)
+    with pytest.raises(Exception):
+        IO.get(str(tmp_path / "x.xyz"))
+
+
+def test_pcn_dataset_items(tree):
+    from imgadapointr_amd.datasets import build_dataset_from_cfg
+    root, clouds = tree
+    base, others = _cfg(root, "train", "PCN")
+    ds = build_dataset_from_cfg(base, others)
+    assert len(ds) == 3
+    tax, mid, (partial, gt) = ds[0]
+    assert tax == "02691156" and mid == "a1"
+    assert partial.shape == (2048, 3) and gt.shape == (16384, 3) and partial.dtype == torch.float32
+    # the mirror augmentation only flips signs of x / z: |gt| is the stored cloud
+    assert np.allclose(np.abs(gt.numpy()), np.abs(clouds[("train", "a1")]), atol=1e-6)
+    base, others = _cfg(root, "val", "PCN")
+    ds = build_dataset_from_cfg(base, others)
+    tax, mid, (partial, gt) = ds[1]
+    assert np.allclose(gt.numpy(), clouds[("val", "c2")], atol=1e-6)     # no augmentation in val
+    nz = int((partial.abs().sum(-1) > 0).sum())
+    assert nz == 2048 or bool((partial[nz:] == 0).all())                 # zero padding at the tail
+
+
+def test_img_and_seg_datasets(tree):
+    from imgadapointr_amd.datasets import build_dataset_from_cfg
+    root, _ = tree
+    base, others = _cfg(root, "val", "ImgPCN", with_img=True)
+    tax, mid, (partial, gt, img) = build_dataset_from_cfg(base, others)[0]
+    assert img.shape == (3, 224, 224) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+    base, others = _cfg(root, "val", "SegImgPCN", with_img=True)
+    ds = build_dataset_from_cfg(base, others)
+    _, _, (partial, gt, img, cls_vec) = ds[0]
+    assert cls_vec.shape == (16,) and cls_vec[0] == 1 and cls_vec.sum() == 1      # airplane -> class 0
+    _, _, (_, _, _, cls_vec) = ds[1]
+    assert cls_vec.sum() == 0                                                     # car: not in SEG_LIST
+
+
+def test_transforms():
+    from imgadapointr_amd.datasets import data_transforms as T
+    np.random.seed(0)
+    pts = np.random.rand(100, 3).astype(np.float32)
+    out = T.RandomSamplePoints({"n_points": 128})(pts.copy())
+    assert out.shape == (128, 3) and (out[100:] == 0).all()
+    assert {tuple(r) for r in out[:100]} == {tuple(r) for r in pts}
+    assert T.UpSamplePoints({"n_points": 350})(pts.copy()).shape == (350, 3)
+    assert T.UpSamplePoints({"n_points": 40})(pts.copy()).shape == (40, 3)
+    m = T.RandomMirrorPoints()
+    assert np.allclose(m(pts.copy(), 0.1), pts * [-1, 1, -1])
+    assert np.allclose(m(pts.copy(), 0.3), pts * [-1, 1, 1])
+    assert np.allclose(m(pts.copy(), 0.6), pts * [1, 1, -1])
+    assert np.allclose(m(pts.copy(), 0.9), pts)
