@@ -164,11 +164,18 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PTOPS_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo — lets the multi-rank code path
+    # (FlatDDP hooks, barriers, max-over-ranks timing) be rehearsed on a one-GPU box.  Never a measurement.
+    rehearsal = os.environ.get("PTOPS_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     _native.load()
     gemm = "library default" if args.no_gemm_tuning else enable_tuned_gemm()
 
@@ -228,7 +235,7 @@ def main():
             "value": round(world * B * args.steps / dt, 3), "unit": "clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
             "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
                                    f"bs={B}/GPU, full train step (BASELINE configs[1])",
                        "global_batch": world * B, "parallelism": f"dp{world}", "gemm_selection": gemm,
