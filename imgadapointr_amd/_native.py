@@ -48,6 +48,7 @@ def _declare(lib):
         "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_emd_forward": (c_int, [P, P, c_int, c_int, c_int] + [P] * 12 + [ctypes.c_float, c_int, P]),
         "ptops_emd_backward": (c_int, [P] * 5 + [c_int] * 3 + [P]),
+        "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -62,6 +63,7 @@ EXPORTS = (
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
+    "ptops_attention_forward",
 )
 
 
@@ -382,3 +384,37 @@ def emd_backward(xyz1, xyz2, gradxyz, graddist, idx):
         _call("ptops_emd_backward", _ptr(xyz1), _ptr(xyz2), _ptr(gradxyz), _ptr(graddist), _ptr(idx), B, n,
               xyz2.shape[1], _stream(xyz1))
     return 1
+
+
+def _bhnd_strides(t, name):
+    """t [B,H,N,64] float32 CUDA view with a contiguous last dim -> ctypes array of (sb, sh, sn)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise PtopsError(f"{name}: expected a float32 GPU tensor [B,H,N,64], got {type(t)} "
+                         f"{getattr(t, 'shape', None)} on {getattr(t, 'device', None)}")
+    if t.size(3) != 64 or t.stride(3) != 1:
+        raise ValueError(f"{name}: head dim must be 64 and contiguous, got shape {tuple(t.shape)} stride {t.stride()}")
+    return (ctypes.c_longlong * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attention_supported(q, k, split_q, limit_k):
+    """True when the fp32 MFMA attention kernel covers this call (else the caller uses SDPA)."""
+    return (q.is_cuda and q.dtype == torch.float32 and q.dim() == 4 and q.size(3) == 64 and k.size(3) == 64
+            and q.size(2) % 32 == 0 and k.size(2) % 32 == 0 and split_q % 32 == 0 and limit_k % 32 == 0
+            and q.stride(3) == 1 and k.stride(3) == 1 and all(s % 4 == 0 for s in q.stride()[:3] + k.stride()[:3])
+            and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0)
+
+
+def attention_forward(q, k, v, split_q, limit_k, scale):
+    """q [B,H,Nq,64], k/v [B,H,Nk,64] (strided views allowed) -> (out [B,Nq,H,64], lse [B,H,Nq])."""
+    if _test_backend is not None:
+        return _test_backend.attention_forward(q, k, v, split_q, limit_k, scale)
+    qs, ks, vs = _bhnd_strides(q, "q"), _bhnd_strides(k, "k"), _bhnd_strides(v, "v")
+    dev = _same_device(q, k, v)
+    B, H, Nq, _ = q.shape
+    Nk = k.size(2)
+    with torch.cuda.device(dev):
+        out = torch.empty((B, Nq, H, 64), dtype=torch.float32, device=dev)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
+        _call("ptops_attention_forward", _ptr(q), _ptr(k), _ptr(v), B, H, Nq, Nk, qs, ks, vs, int(split_q),
+              int(limit_k), ctypes.c_float(float(scale)), _ptr(out), _ptr(lse), _stream(q))
+    return out, lse

@@ -1,0 +1,226 @@
+// fp32 multi-head attention (forward + backward) on the f32 MFMA path of gfx950 (MI355X).
+//
+// Replaces the softmax(q k^T * scale [+ block mask]) v chain of Attention / CrossAttention
+// (models/Transformer_utils.py:89-159 of the reference) for the shapes of the AdaPoinTr path:
+// head_dim 64, token counts that are multiples of 32 (256 / 512 / 576), and the denoise mask of
+// base_blocks.py:224-229, which is block-aligned (the first `split_q` queries see only the first
+// `limit_k` keys; the remaining queries see every key) and therefore needs no per-element masking.
+//
+// Everything is exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, the softmax is the
+// usual online (running max / running sum) form.
+//
+// Forward, one wave per 32-query tile, W waves per workgroup sharing LDS K/V tiles of 32 keys:
+//   S^T = K Q^T   : A = K tile from LDS (lane (i,h): key i, dims 32h..32h+31 -> 8 ds_read_b128, rows
+//                   padded to 68 dwords so that the 16-lane read groups hit 16 distinct 16-byte slots),
+//                   B = Q^T held in 32 VGPRs for the whole kernel (pre-scaled by scale*log2 e).
+//                   The contraction order over the 64 dims is permuted (half h of the wave covers dims
+//                   32h+s) so that both operands are contiguous per lane.
+//   softmax       : with S^T the query sits on the lane and its 32 keys in 16 registers x 2 lane
+//                   halves, so row max / row sum are register reductions plus ONE cross-half exchange.
+//   O^T = V^T P   : B = P is the S^T accumulator itself (k-step r consumes the keys that register r
+//                   holds in the two halves: no data movement), A = V^T from LDS (conflict-free
+//                   ds_read_b32 across dims).
+#include <math.h>
+
+#include "ptops_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 64;        // head dim
+constexpr int kTK = 32;       // keys per LDS tile
+constexpr int kLd = 68;       // padded row stride (dwords) of the LDS tiles
+
+struct AttnArgs {
+  const float* q;  // element (b,h,n,c) at q + b*q_sb + h*q_sh + n*q_sn + c
+  const float* k;
+  const float* v;
+  float* o;        // [B, Nq, H, 64] contiguous
+  float* lse;      // [B, H, Nq]  (base-2 log-sum-exp of the scaled scores)
+  long long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn;
+  int H, Nq, Nk;
+  int split_q, limit_k;  // queries < split_q attend to keys < limit_k; the others to all Nk
+  float scale_log2e;
+};
+
+__device__ __forceinline__ float other_half(float x) {
+  // value held by lane ^ 32
+  return __shfl_xor(x, 32);
+}
+
+// __launch_bounds__(.., 3): at most 168 VGPR+AGPR, i.e. three waves per SIMD.
+template <int W>
+__global__ __launch_bounds__(W * 64, 3) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sK[2][kTK * kLd];
+  __shared__ __attribute__((aligned(16))) float sV[2][kTK * kLd];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int q0 = (blockIdx.x * W + wave) * 32;
+  const bool active = q0 < a.Nq;  // wave-uniform
+  const float* qb = a.q + b * a.q_sb + head * a.q_sh;
+  const float* kb = a.k + b * a.k_sb + head * a.k_sh;
+  const float* vb = a.v + b * a.v_sb + head * a.v_sh;
+
+  // keys this workgroup has to walk: the maximum over its waves' tiles (block-uniform)
+  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
+  const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
+  const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
+
+  // B operand of S^T = K Q^T: lane (j,h) holds Q[q0+j][32h + s], s = 0..31, pre-scaled
+  float qf[32];
+  if (active) {
+    const float* qp = qb + (long long)(q0 + j) * a.q_sn + 32 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(qp + 4 * t);
+      qf[4 * t + 0] = v4.x * a.scale_log2e;
+      qf[4 * t + 1] = v4.y * a.scale_log2e;
+      qf[4 * t + 2] = v4.z * a.scale_log2e;
+      qf[4 * t + 3] = v4.w * a.scale_log2e;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) qf[t] = 0.0f;
+  }
+
+  f32x16 o0 = {0}, o1 = {0};  // O^T accumulators: dims 0..31 and 32..63, query on the lane
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  // Cooperative tile staging, split in two halves so that the global loads of tile t+1 are in
+  // flight while tile t is being multiplied: fetch -> registers before the MFMAs, registers -> LDS after.
+  constexpr int kPerThread = (kTK * (kD / 4) + W * 64 - 1) / (W * 64);  // float4 per thread per matrix
+  f32x4 kreg[kPerThread], vreg[kPerThread];
+  auto fetch_tile = [&](int key0) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        kreg[u] = *reinterpret_cast<const f32x4*>(kb + (long long)(key0 + r) * a.k_sn + c4);
+        vreg[u] = *reinterpret_cast<const f32x4*>(vb + (long long)(key0 + r) * a.v_sn + c4);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<f32x4*>(&sK[buf][r * kLd + c4]) = kreg[u];
+        *reinterpret_cast<f32x4*>(&sV[buf][r * kLd + c4]) = vreg[u];
+      }
+    }
+  };
+
+  const int ntiles = blk_keys / kTK;
+  if (ntiles > 0) {
+    fetch_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    if (t * kTK < my_keys) {
+      // ---- S^T = K Q^T ------------------------------------------------------------------
+      f32x16 s = {0};
+      const float* kr = &sK[buf][j * kLd + 32 * h];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + 4 * g);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[4 * g + 0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[4 * g + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[4 * g + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[4 * g + 3], s, 0, 0, 0);
+      }
+      // ---- online softmax (query = lane&31; this half holds 16 of the tile's 32 keys) ------
+      float mt = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+      mt = fmaxf(mt, other_half(mt));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += s[r];
+      }
+      l_run = l_run * alpha + psum;  // per-half partial sum; halves are added at the end
+      m_run = m_new;
+      o0 *= alpha;
+      o1 *= alpha;
+      // ---- O^T += V^T P : k-step r uses keys (r&3)+8(r>>2) [half 0] and +4 [half 1] ---------
+      const float* vr = &sV[buf][(4 * h) * kLd + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2);
+        const float v0 = vr[key * kLd], v1 = vr[key * kLd + 32];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active) {
+    const float l_tot = l_run + other_half(l_run);
+    const float inv = 1.0f / l_tot;
+    // accumulator layout: column = query (lane&31), row(reg) = (reg&3) + 8*(reg>>2) + 4*h = dim
+    float* op = a.o + (((long long)b * a.Nq + q0 + j) * a.H + head) * kD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w0 = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      f32x4 w1 = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * h) = w0;
+      *reinterpret_cast<f32x4*>(op + 32 + 8 * g + 4 * h) = w1;
+    }
+    if (h == 0) a.lse[((long long)b * a.H + head) * a.Nq + q0 + j] = m_run + __builtin_amdgcn_logf(l_tot);
+  }
+}
+
+}  // namespace
+
+PTOPS_API int ptops_attention_forward(const float* q, const float* k, const float* v, int B, int H, int Nq,
+                                      int Nk, const long long* q_strides, const long long* k_strides,
+                                      const long long* v_strides, int split_q, int limit_k, float scale,
+                                      float* out, float* lse, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && H >= 1 && Nq >= 0 && Nk >= 1, "attention_forward: bad size");
+  if (B == 0 || Nq == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(q && k && v && out && lse && q_strides && k_strides && v_strides, "attention_forward: null pointer");
+  PTOPS_REQUIRE(Nq % 32 == 0 && Nk % 32 == 0, "attention_forward: token counts must be multiples of 32 (Nq=%d Nk=%d)", Nq, Nk);
+  PTOPS_REQUIRE(split_q >= 0 && split_q <= Nq && split_q % 32 == 0 && limit_k >= 32 && limit_k <= Nk && limit_k % 32 == 0,
+                "attention_forward: mask split (%d, %d) must be multiples of 32 within range", split_q, limit_k);
+  for (int i = 0; i < 3; ++i)
+    PTOPS_REQUIRE(q_strides[i] % 4 == 0 && k_strides[i] % 4 == 0 && v_strides[i] % 4 == 0,
+                  "attention_forward: strides must keep rows 16-byte aligned");
+  PTOPS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0,
+                "attention_forward: pointers must be 16-byte aligned");
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = out; a.lse = lse;
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
+  a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
+  a.scale_log2e = scale * 1.4426950408889634f;
+  const int tiles = Nq / 32;
+  // waves per workgroup: the largest of {4,3,2} that divides the number of query tiles (576 -> 3)
+  int W = tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : (tiles % 2 == 0 ? 2 : 1));
+  if (W == 4 && (long long)(tiles / 4) * B * H < 3 * ptops::kNumCU) W = 2;  // short sequences: more, smaller workgroups
+  dim3 grid(tiles / W, B * H);
+  switch (W) {
+    case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(192), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(128), 0, stream, a); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(64), 0, stream, a); break;
+  }
+  return ptops::check_launch("attn_fwd_kernel");
+}

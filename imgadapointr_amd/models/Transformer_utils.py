@@ -24,6 +24,12 @@ FUSED_GRAPH_ATTENTION = True
 # Attention evaluation: F.scaled_dot_product_attention (True) or the reference's explicit
 # softmax(q k^T) v chain (False).
 USE_SDPA = True
+# Forward of head-dim-64 attention on libptops' fp32 MFMA kernel (csrc/attention.hip), backward on
+# PyTorch-ROCm's memory-efficient attention backward (aten::_efficient_attention_backward), which
+# consumes the same (out, logsumexp) pair.  Falls back to SDPA for shapes the kernel does not cover.
+USE_MFMA_ATTENTION = True
+_LN2 = 0.6931471805599453
+_bias_cache = {}
 
 
 # Linear layers whose input is cat([per-cloud vector broadcast over tokens, per-token features]):
@@ -124,8 +130,56 @@ class Mlp(nn.Module):
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
-def _attend(q, k, v, scale, mask, attn_drop):
-    """q [B,h,N,d], k/v [B,h,M,d]; mask bool [N,M] with True = blocked (reference convention)."""
+def _block_bias(nq, nk, split_q, limit_k, device):
+    """Additive [nq,nk] bias of the block mask (0 / -inf), cached per shape and device."""
+    key = (nq, nk, split_q, limit_k, str(device))
+    b = _bias_cache.get(key)
+    if b is None:
+        b = torch.zeros(nq, nk, device=device)
+        b[:split_q, limit_k:] = float('-inf')
+        _bias_cache[key] = b
+    return b
+
+
+class _MFMAAttention(torch.autograd.Function):
+    """out[B,N,h,d] = softmax(q k^T scale + block mask) v; q/k/v are [B,h,N,64] (strided views)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, split_q, limit_k, scale):
+        out, lse2 = _native.attention_forward(q, k, v, split_q, limit_k, scale)
+        ctx.save_for_backward(q, k, v, out, lse2)
+        ctx.mask, ctx.scale = (split_q, limit_k), scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, out, lse2 = ctx.saved_tensors
+        split_q, limit_k = ctx.mask
+        B, H, Nq, _ = q.shape
+        Nk = k.size(2)
+        bias = None
+        if split_q > 0 and limit_k < Nk:
+            bias = _block_bias(Nq, Nk, split_q, limit_k, q.device).expand(B, H, Nq, Nk)
+        zero = torch.zeros((), dtype=torch.int64, device=q.device)
+        gq, gk, gv, _ = torch.ops.aten._efficient_attention_backward(
+            grad_out.contiguous(), q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), bias, out, None, None,
+            Nq, Nk, lse2 * _LN2, 0.0, zero, zero, 0, False, scale=ctx.scale)
+        return gq.transpose(1, 2), gk.transpose(1, 2), gv.transpose(1, 2), None, None, None
+
+
+def _attend(q, k, v, scale, mask, attn_drop, mask_split=None):
+    """q [B,h,N,d], k/v [B,h,M,d]; mask bool [N,M] with True = blocked (reference convention);
+    mask_split = (split_q, limit_k) when the mask is the block mask "queries < split_q do not see
+    keys >= limit_k".  Returns [B,N,h,d]."""
+    no_drop = attn_drop.p == 0.0 or not attn_drop.training
+    if USE_MFMA_ATTENTION and no_drop and (mask is None or mask_split is not None):
+        split_q, limit_k = mask_split if mask_split is not None else (0, k.size(2))
+        if _native.backend_for_testing() is None and _native.attention_supported(q, k, split_q, limit_k):
+            return _MFMAAttention.apply(q, k, v, split_q, limit_k, scale)
+    return _attend_torch(q, k, v, scale, mask, attn_drop).transpose(1, 2)
+
+
+def _attend_torch(q, k, v, scale, mask, attn_drop):
     if USE_SDPA and (attn_drop.p == 0.0 or not attn_drop.training):
         keep = None if mask is None else ~mask
         return F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=scale)
@@ -149,14 +203,15 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, mask_split=None):
+        """mask: [N,N], > 0 = blocked (reference semantics).  mask_split = (split_q, limit_k), optional:
+        tells that `mask` is the block mask "queries < split_q do not see keys >= limit_k"."""
         B, N, C = x.shape
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         if mask is not None:
             mask = mask > 0  # 1 = blocked
-        x = _attend(q, k, v, self.scale, mask, self.attn_drop)
-        x = x.transpose(1, 2).reshape(B, N, C)
+        x = _attend(q, k, v, self.scale, mask, self.attn_drop, mask_split).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 
 
@@ -186,8 +241,7 @@ class CrossAttention(nn.Module):
         q = self.q_map(q).view(B, N, h, C // h).permute(0, 2, 1, 3)
         k = self.k_map(k).view(B, NK, h, C // h).permute(0, 2, 1, 3)
         v = self.v_map(v).view(B, NK, h, C // h).permute(0, 2, 1, 3)
-        x = _attend(q, k, v, self.scale, None, self.attn_drop)
-        x = x.transpose(1, 2).reshape(B, N, C)
+        x = _attend(q, k, v, self.scale, None, self.attn_drop).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 
 

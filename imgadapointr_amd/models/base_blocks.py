@@ -192,21 +192,22 @@ class CrossAttnBlockApi(nn.Module):
         # Denoise mask (base_blocks.py:224-229): 1 = blocked; the real queries (rows [:-dl]) may not
         # attend to the denoise tokens (columns [-dl:]); denoise tokens see everything.
         if denoise_length is None:
-            mask = None
+            mask = mask_split = None
         else:
             n = q.size(1)
             mask = torch.zeros(n, n, device=q.device)
             mask[:-denoise_length, -denoise_length:] = 1.
+            mask_split = (n - denoise_length, n - denoise_length)
 
         if self.self_attn_block_length == 2 and self.self_attn_combine_style == 'onebyone':
-            q = q + self.drop_path1(self.ls1(self.self_attn(self.norm1(q), mask=mask)))
+            q = q + self.drop_path1(self.ls1(self.self_attn(self.norm1(q), mask=mask, mask_split=mask_split)))
             q = q + self.drop_path3(self.ls3(self.local_self_attn(
                 self.norm3(q), q_pos, idx=self_attn_idx, denoise_length=denoise_length)))
         else:
             norm_q = self.norm1(q)
             feats = []
             if self.self_attn is not None:
-                feats.append(self.self_attn(norm_q, mask=mask))
+                feats.append(self.self_attn(norm_q, mask=mask, mask_split=mask_split))
             if self.local_self_attn is not None:
                 feats.append(self.local_self_attn(norm_q, q_pos, idx=self_attn_idx, denoise_length=denoise_length))
             if len(feats) != self.self_attn_block_length:

@@ -139,6 +139,20 @@ int ptops_emd_backward(const float* xyz1, const float* xyz2, float* gradxyz,
                        const float* graddist, const int32_t* idx, int B, int n, int m,
                        void* stream);
 
+/* --------------------------------------------------------------- attention --
+ * softmax(q k^T * scale [+ block mask]) v of Attention / CrossAttention
+ * (models/Transformer_utils.py:89-159), fp32, head_dim 64, on the f32 MFMA path.
+ *   q [B,H,Nq,64], k/v [B,H,Nk,64] given by base pointer + element strides
+ *   {batch, head, token} (innermost dim contiguous), Nq and Nk multiples of 32.
+ *   Mask (base_blocks.py:224-229): queries < split_q attend to keys < limit_k, the
+ *   rest to all keys; split_q = 0, limit_k = Nk means no mask; both multiples of 32.
+ *   out [B,Nq,H,64] contiguous; lse [B,H,Nq] (base-2 log-sum-exp, kept for backward). */
+int ptops_attention_forward(const float* q, const float* k, const float* v, int B, int H,
+                            int Nq, int Nk, const long long* q_strides,
+                            const long long* k_strides, const long long* v_strides,
+                            int split_q, int limit_k, float scale, float* out, float* lse,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,17 +134,54 @@ def check_blocks(device, tol=3e-5):
     return worst
 
 
+def _match_rows(got, want):
+    """Permutation p with got[i] ~ want[p[i]] (nearest row; must be a bijection)."""
+    d = ((got[:, None, :].astype(np.float64) - want[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    p = d.argmin(1)
+    assert len(set(p.tolist())) == len(p), "rows do not match one-to-one"
+    return p
+
+
+def compare_ranked(coarse, fine_head, want_coarse, want_fine_head, tol, factor=32):
+    """max deviations of ranked-query outputs [B,M,3] / [B,K*factor,3] after matching query rows.
+    `*_fine_head` hold the points of the first K queries; groups whose query kept its rank are compared."""
+    dc = df = 0.0
+    swapped = 0
+    for b in range(coarse.shape[0]):
+        p = _match_rows(coarse[b], want_coarse[b])
+        swapped += int((p != np.arange(len(p))).sum())
+        dc = max(dc, maxdiff(coarse[b], want_coarse[b][p]))
+        K = fine_head.shape[1] // factor
+        keep = np.nonzero(p[:K] == np.arange(K))[0]
+        got = fine_head[b].reshape(K, factor, 3)[keep]
+        want = want_fine_head[b].reshape(K, factor, 3)[keep]
+        df = max(df, maxdiff(got, want))
+    assert dc < tol and df < tol, (dc, df)
+    assert swapped <= 8, swapped
+    return dc, df, swapped
+
+
 def check_eval_forward(device, tol=2e-4):
+    """Eval forward vs the reference fixture.  The 512 queries are the top-ranked of 768 proposals
+    (argsort of a learned score, AdaPoinTr.py:119-121); two scores closer than float rounding may swap
+    places between implementations, so rows are matched before comparing (values must still agree)."""
     g = load("adapointr.npz")
     model, _ = build_adapointr(device)
     model.eval()
     with torch.no_grad():
         coarse, fine = model(t(g["partial"], device))
-    dc = maxdiff(coarse.cpu().numpy(), g["eval_coarse"])
-    df = maxdiff(fine.cpu().numpy(), g["eval_fine"])
+    coarse, fine = coarse.cpu().numpy(), fine.cpu().numpy()
+    dc = df = 0.0
+    swapped = 0
+    for b in range(coarse.shape[0]):
+        p = _match_rows(coarse[b], g["eval_coarse"][b])
+        swapped += int((p != np.arange(len(p))).sum())
+        dc = max(dc, maxdiff(coarse[b], g["eval_coarse"][b][p]))
+        want_fine = g["eval_fine"][b].reshape(len(p), -1, 3)[p].reshape(-1, 3)
+        df = max(df, maxdiff(fine[b], want_fine))
     assert dc < tol and df < tol, (dc, df)
-    # the results metric: CD-L1 x1000 of the completion against the fixture's own fine cloud
-    return dc, df
+    assert swapped <= 8, swapped
+    return dc, df, swapped
 
 
 def check_train_forward_and_loss(device, tol=2e-4):
@@ -153,10 +190,10 @@ def check_train_forward_and_loss(device, tol=2e-4):
     model, _ = build_adapointr(device)
     model.train()
     ret = model(t(g["partial"], device), denoise_noise=t(g["train_noise"], device))
-    names = ("pred_coarse", "denoised_coarse", "denoised_fine")
-    for r, n in zip(ret[:3], names):
+    for r, n in zip(ret[1:3], ("denoised_coarse", "denoised_fine")):
         assert maxdiff(r.detach().cpu().numpy(), g[n]) < tol, n
-    assert maxdiff(ret[3][:, :2048].detach().cpu().numpy(), g["pred_fine_head"]) < tol
+    compare_ranked(ret[0].detach().cpu().numpy(), ret[3][:, :2048].detach().cpu().numpy(), g["pred_coarse"],
+                   g["pred_fine_head"], tol)
     l_den, l_rec = model.get_loss(ret, t(g["gt"], device))
     # CD-L1 x1000 within 1e-3 of the reference path (BASELINE.json north_star)
     assert abs(l_den.item() * 1000 - float(g["loss_denoised"]) * 1000) < 1e-3
@@ -219,11 +256,12 @@ def check_img_model(device, tol=3e-4):
     model.eval()
     with torch.no_grad():
         coarse, fine = model(partial, img)
-    d_eval = (maxdiff(coarse.cpu().numpy(), g["eval_coarse"]), maxdiff(fine[:, :4096].cpu().numpy(), g["eval_fine_head"]))
-    assert max(d_eval) < tol, d_eval
+    d_eval = compare_ranked(coarse.cpu().numpy(), fine[:, :4096].cpu().numpy(), g["eval_coarse"],
+                            g["eval_fine_head"], tol)
     model.train()
     ret = model(partial, img, denoise_noise=t(g["train_noise"], device))
-    d_train = (maxdiff(ret[0].detach().cpu().numpy(), g["pred_coarse"]),
+    d_train = (compare_ranked(ret[0].detach().cpu().numpy(), np.zeros((1, 0, 3), np.float32), g["pred_coarse"],
+                              np.zeros((1, 0, 3), np.float32), tol)[0],
                maxdiff(ret[2][:, :512].detach().cpu().numpy(), g["denoised_fine_head"]))
     assert max(d_train) < tol, d_train
     gt = t(synthetic_batch(1, 2048, 16384, seed=23, structured=True)[1], device)
@@ -275,6 +313,6 @@ def check_seg_branch(device, tol=3e-4):
     img = t(synthetic_image(1, seed=22), device)
     with torch.no_grad():
         coarse, fine = model(partial, img, cls)
-    d_m = (maxdiff(coarse.cpu().numpy(), g["eval_coarse"]), maxdiff(fine[:, :4096].cpu().numpy(), g["eval_fine_head"]))
-    assert max(d_m) < tol, d_m
+    d_m = compare_ranked(coarse.cpu().numpy(), fine[:, :4096].cpu().numpy(), g["eval_coarse"],
+                         g["eval_fine_head"], tol)
     return d_n, d_g, d_m

@@ -211,3 +211,45 @@ def test_metrics_with_emd(native, ref):
     d1, d2, _, _ = ref.chamfer_forward(pred, gt)
     p, r = (np.sqrt(d1) < 0.01).mean(), (np.sqrt(d2) < 0.01).mean()
     assert abs(vals[0] - (2 * p * r / (p + r) if p + r else 0.0)) < 1e-6
+
+
+@pytest.mark.parametrize("Nq,Nk,split,limit", [(576, 576, 512, 512), (576, 256, 0, 256), (256, 256, 0, 256),
+                                                (512, 512, 0, 512), (96, 64, 32, 32), (32, 32, 0, 32)])
+def test_attention_forward_and_backward(native, Nq, Nk, split, limit):
+    """fp32 MFMA attention vs an explicit float64 softmax(q k^T scale + mask) v, values and gradients."""
+    from imgadapointr_amd.models.Transformer_utils import _MFMAAttention
+    torch.manual_seed(Nq + Nk)
+    B, H, d = 3, 6, 64
+    qkv = torch.randn(B, Nq, 3, H, d, device="cuda", requires_grad=True)     # strided q view, as in Attention
+    kv = torch.randn(B, Nk, 2, H, d, device="cuda", requires_grad=True)
+    q = qkv.permute(2, 0, 3, 1, 4)[0]
+    k, v = kv.permute(2, 0, 3, 1, 4)[0], kv.permute(2, 0, 3, 1, 4)[1]
+    scale = d ** -0.5
+    assert native.attention_supported(q, k, split, limit)
+    out = _MFMAAttention.apply(q, k, v, split, limit, scale)                  # [B,Nq,H,d]
+    go = torch.randn_like(out)
+    g = torch.autograd.grad(out, (qkv, kv), go)
+
+    q64, k64, v64 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    a = (q64 @ k64.transpose(-1, -2)) * scale
+    if split:
+        blocked = torch.zeros(Nq, Nk, dtype=torch.bool, device="cuda")
+        blocked[:split, limit:] = True
+        a = a.masked_fill(blocked, float("-inf"))
+    gold = a.softmax(-1) @ v64                                                # [B,H,Nq,d]
+    gq, gk, gv = torch.autograd.grad(gold, (q64, k64, v64), go.permute(0, 2, 1, 3).double())
+    # fp32 accumulation over <= 576 keys: a few 1e-6 absolute on O(1) values
+    assert (out.permute(0, 2, 1, 3).double() - gold).abs().max().item() < 5e-6
+    assert (g[0][:, :, 0].double() - gq.permute(0, 2, 1, 3)).abs().max().item() < 2e-5
+    assert (g[0][:, :, 1:].abs().max().item()) == 0.0                        # only the q slice receives gradient
+    assert (g[1][:, :, 0].double() - gk.permute(0, 2, 1, 3)).abs().max().item() < 2e-5
+    assert (g[1][:, :, 1].double() - gv.permute(0, 2, 1, 3)).abs().max().item() < 2e-5
+
+
+def test_attention_rejects_unsupported_shapes(native):
+    q = torch.randn(1, 2, 40, 64, device="cuda")
+    assert not native.attention_supported(q, q, 0, 40)                        # 40 is not a multiple of 32
+    with pytest.raises(Exception):
+        native.attention_forward(q, q, q, 0, 40, 0.125)
+    q48 = torch.randn(1, 2, 64, 48, device="cuda")
+    assert not native.attention_supported(q48, q48, 0, 64)
