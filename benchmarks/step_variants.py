@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--tunable", action="store_true")
     ap.add_argument("--tunable-file", default="gpurun_out/tunableop.csv")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--tune-ms", type=int, default=30)
+    ap.add_argument("--tune-iters", type=int, default=20)
+    ap.add_argument("--skip-ab", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = load_cfg()
@@ -52,13 +55,15 @@ def main():
         "hipblaslt": dict(blas="hipblaslt"),
     }
     res = {k: [] for k in variants}
-    for rnd in range(3):
+    for rnd in range(0 if a.skip_ab else 3):
         for name, v in variants.items():
             setv(**v)
             time_steps(step, partial, gt, 2)
             res[name].append(time_steps(step, partial, gt, a.steps))
     setv(blas="default")
     for k, ts in res.items():
+        if not ts:
+            continue
         print(f"{k:32s} min {min(ts):7.2f} ms  med {sorted(ts)[1]:7.2f} ms")
     print("preferred blas now:", torch.backends.cuda.preferred_blas_library())
 
@@ -66,8 +71,8 @@ def main():
         setv()
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
-        torch.cuda.tunable.set_max_tuning_duration(30)
-        torch.cuda.tunable.set_max_tuning_iterations(20)
+        torch.cuda.tunable.set_max_tuning_duration(a.tune_ms)
+        torch.cuda.tunable.set_max_tuning_iterations(a.tune_iters)
         torch.cuda.tunable.set_filename(a.tunable_file)
         t0 = time.perf_counter()
         time_steps(step, partial, gt, 2)
@@ -75,7 +80,6 @@ def main():
         torch.cuda.tunable.tuning_enable(False)
         ts = [time_steps(step, partial, gt, a.steps) for _ in range(3)]
         print(f"{'tunableop(tuned)':32s} min {min(ts):7.2f} ms  med {sorted(ts)[1]:7.2f} ms")
-        torch.cuda.tunable.write_file(a.tunable_file)
         print("tunable results:", len(torch.cuda.tunable.get_results()))
 
 

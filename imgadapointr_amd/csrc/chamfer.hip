@@ -281,10 +281,17 @@ Plan make_plan(int B, int n, int m) {
   return p;
 }
 
+// Path choice, a pure function of the sizes: the pruned sweep when both clouds can be sorted in one
+// workgroup, else brute force.  (Tuning builds can force brute force with PTOPS_TUNE_SWEEP=0.)
+bool use_sweep(int B, int n, int m) {
+  return ptops_sweep::eligible(B, n, m) && env_int("PTOPS_TUNE_SWEEP", 1) != 0;
+}
+
 }  // namespace
 
 PTOPS_API size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
+  if (use_sweep(B, n, m)) return ptops_sweep::workspace_bytes(B, n, m);
   Plan p = make_plan(B, n, m);
   return p.need_ws ? sizeof(unsigned long long) * (size_t)B * ((size_t)n + m) : 0;
 }
@@ -304,6 +311,15 @@ PTOPS_API int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B,
   PTOPS_REQUIRE(xyz1 && xyz2, "chamfer_forward: null input");
   PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
                 "chamfer_forward: B*n*3 must fit int32");
+  if (use_sweep(B, n, m)) {
+    PTOPS_REQUIRE(workspace != nullptr, "chamfer_forward: workspace required (%zu bytes)",
+                  ptops_sweep::workspace_bytes(B, n, m));
+    if (((uintptr_t)workspace & 15) != 0) {
+      ptops::set_error("chamfer_forward: workspace must be 16-byte aligned");
+      return PTOPS_EALIGN;
+    }
+    return ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, stream);
+  }
   const Plan p = make_plan(B, n, m);
   unsigned long long* ws = (unsigned long long*)workspace;
   if (p.need_ws) {

@@ -1,39 +1,41 @@
-"""Running value / sum / count meters (interface of utils/AverageMeter.py in the reference)."""
+"""Running last-value / mean trackers for one or several named quantities.
+
+Call surface of utils/AverageMeter.py of the reference: AverageMeter(items=None) with
+update(value | list), val(idx=None), count(idx=None), avg(idx=None), reset().
+"""
+import numpy as np
 
 
 class AverageMeter(object):
     def __init__(self, items=None):
         self.items = items
-        self.n_items = 1 if items is None else len(items)
+        self.n_items = len(items) if items is not None else 1
         self.reset()
 
     def reset(self):
-        self._val = [0] * self.n_items
-        self._sum = [0] * self.n_items
-        self._count = [0] * self.n_items
+        self._stats = np.zeros((3, self.n_items), dtype=np.float64)  # rows: last value, sum, count
 
     def update(self, values):
-        if isinstance(values, list):
-            for i, v in enumerate(values):
-                self._val[i] = v
-                self._sum[i] += v
-                self._count[i] += 1
-        else:
-            self._val[0] = values
-            self._sum[0] += values
-            self._count[0] += 1
+        vals = values if isinstance(values, list) else [values]
+        for i, v in enumerate(vals):
+            self._stats[0, i] = v
+            self._stats[1, i] += v
+            self._stats[2, i] += 1
 
-    def _pick(self, arr, idx):
+    def _select(self, row, idx, as_int=False):
+        conv = (lambda x: int(x)) if as_int else (lambda x: float(x))
         if idx is not None:
-            return arr[idx]
-        return arr[0] if self.items is None else list(arr)
+            return conv(row[idx])
+        if self.items is None:
+            return conv(row[0])
+        return [conv(x) for x in row]
 
     def val(self, idx=None):
-        return self._pick(self._val, idx)
+        return self._select(self._stats[0], idx)
 
     def count(self, idx=None):
-        return self._pick(self._count, idx)
+        return self._select(self._stats[2], idx, as_int=True)
 
     def avg(self, idx=None):
-        means = [s / c if c else 0.0 for s, c in zip(self._sum, self._count)]
-        return self._pick(means, idx)
+        cnt = np.maximum(self._stats[2], 1)
+        return self._select(self._stats[1] / cnt, idx)

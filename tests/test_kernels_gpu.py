@@ -20,6 +20,18 @@ def _cloud(rng, B, n, kind="uniform"):
         v *= (0.3 + 0.2 * rng.random((B, n, 1), dtype=np.float32))
         v[:, n - n // 4:, :] = 0.0
         return v.astype(np.float32)
+    if kind == "lattice":  # integer grid: masses of exactly equal distances between DISTINCT points
+        g = rng.integers(0, 12, size=(B, n, 3)).astype(np.float32) * np.float32(0.0625) - np.float32(0.375)
+        return g
+    if kind == "clusters":  # a few tight blobs far apart (pruning-hostile for the far cloud)
+        centres = rng.random((B, 6, 3), dtype=np.float32) - 0.5
+        pick = rng.integers(0, 6, size=(B, n))
+        pts = np.take_along_axis(centres, pick[..., None].repeat(3, -1), axis=1)
+        return (pts + rng.standard_normal((B, n, 3)).astype(np.float32) * np.float32(0.004)).astype(np.float32)
+    if kind == "plane":  # every point on one x: the sweep can prune nothing
+        v = rng.random((B, n, 3), dtype=np.float32) - 0.5
+        v[..., 0] = np.float32(0.25)
+        return v
     if kind == "dups":  # heavy duplication -> exact distance ties
         base = (rng.random((B, max(n // 8, 1), 3), dtype=np.float32) - 0.5)
         idx = rng.integers(0, base.shape[1], size=(B, n))
@@ -35,6 +47,9 @@ CHAMFER_CASES = [
     (2, 64, 128, "uniform"), (4, 2048, 2048, "uniform"), (3, 512, 16384, "uniform"),
     (2, 16384, 16384, "uniform"), (1, 1, 1, "uniform"), (1, 1, 777, "uniform"), (2, 300, 17, "uniform"),
     (2, 1000, 999, "dups"), (2, 2048, 4096, "shell"), (1, 5000, 3, "uniform"), (32, 512, 2048, "uniform"),
+    # the pruned sweep path (both clouds in [1024, 16384]): ties, clusters, degenerate x, ragged sizes
+    (2, 4096, 4096, "lattice"), (2, 2048, 3000, "dups"), (2, 8192, 2048, "clusters"), (2, 1024, 16384, "plane"),
+    (3, 1025, 1039, "uniform"), (1, 16384, 16384, "shell"), (2, 3000, 5000, "lattice"), (1, 16383, 1024, "clusters"),
 ]
 
 
@@ -48,6 +63,18 @@ def test_chamfer_forward_bit_exact(native, ref, B, n, m, kind):
     assert np.array_equal(d2.cpu().numpy().view(np.uint32), r2.view(np.uint32))
     assert np.array_equal(i1.cpu().numpy(), j1)
     assert np.array_equal(i2.cpu().numpy(), j2)
+
+
+def test_chamfer_mixed_kinds(native, ref):
+    """Queries and candidates of different structure (uniform gt vs clustered / lattice predictions)."""
+    rng = np.random.default_rng(99)
+    for ka, kb, n, m in (("uniform", "clusters", 16384, 16384), ("lattice", "uniform", 4096, 8192),
+                         ("clusters", "lattice", 2048, 2048)):
+        a, b = _cloud(rng, 2, n, ka), _cloud(rng, 2, m, kb)
+        got = native.chamfer_forward(_t(a), _t(b))
+        want = ref.chamfer_forward(a, b)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), w), (ka, kb)
 
 
 def test_chamfer_identity(native):
