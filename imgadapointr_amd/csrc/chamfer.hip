@@ -289,17 +289,40 @@ bool use_sweep(int B, int n, int m) {
 
 }  // namespace
 
-PTOPS_API size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m) {
-  if (B <= 0 || n <= 0 || m <= 0) return 0;
-  if (use_sweep(B, n, m)) return ptops_sweep::workspace_bytes(B, n, m);
+static size_t brute_workspace_bytes(int B, int n, int m) {
   Plan p = make_plan(B, n, m);
   return p.need_ws ? sizeof(unsigned long long) * (size_t)B * ((size_t)n + m) : 0;
 }
 
+PTOPS_API size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m) {
+  if (B <= 0 || n <= 0 || m <= 0) return 0;
+  // large enough for either algorithm, so that a caller may switch between them per call
+  const size_t a = brute_workspace_bytes(B, n, m);
+  const size_t b = use_sweep(B, n, m) ? ptops_sweep::workspace_bytes(B, n, m) : 0;
+  return a > b ? a : b;
+}
+
+PTOPS_API int ptops_chamfer_sweep_available(int B, int n, int m) {
+  return (B > 0 && n > 0 && m > 0 && use_sweep(B, n, m)) ? 1 : 0;
+}
+
+PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1,
+                                       float* dist2, int32_t* idx1, int32_t* idx2, void* workspace,
+                                       int algorithm, unsigned long long* stats, void* stream_);
+
 PTOPS_API int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, int m,
                                     float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
                                     void* workspace, void* stream_) {
+  return ptops_chamfer_forward_ex(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, PTOPS_CHAMFER_AUTO,
+                                  nullptr, stream_);
+}
+
+PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1,
+                                       float* dist2, int32_t* idx1, int32_t* idx2, void* workspace,
+                                       int algorithm, unsigned long long* stats, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(algorithm == PTOPS_CHAMFER_AUTO || algorithm == PTOPS_CHAMFER_BRUTE || algorithm == PTOPS_CHAMFER_SWEEP,
+                "chamfer_forward: unknown algorithm %d", algorithm);
   PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_forward: negative size");
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(dist1 && dist2 && idx1 && idx2, "chamfer_forward: null output");
@@ -311,20 +334,21 @@ PTOPS_API int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B,
   PTOPS_REQUIRE(xyz1 && xyz2, "chamfer_forward: null input");
   PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
                 "chamfer_forward: B*n*3 must fit int32");
-  if (use_sweep(B, n, m)) {
+  PTOPS_REQUIRE(algorithm != PTOPS_CHAMFER_SWEEP || use_sweep(B, n, m),
+                "chamfer_forward: the sweep needs both clouds within [4096, 16384] points (n=%d m=%d)", n, m);
+  if (algorithm != PTOPS_CHAMFER_BRUTE && use_sweep(B, n, m)) {
     PTOPS_REQUIRE(workspace != nullptr, "chamfer_forward: workspace required (%zu bytes)",
                   ptops_sweep::workspace_bytes(B, n, m));
     if (((uintptr_t)workspace & 15) != 0) {
       ptops::set_error("chamfer_forward: workspace must be 16-byte aligned");
       return PTOPS_EALIGN;
     }
-    return ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, stream);
+    return ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, stats, stream);
   }
   const Plan p = make_plan(B, n, m);
   unsigned long long* ws = (unsigned long long*)workspace;
   if (p.need_ws) {
-    PTOPS_REQUIRE(ws != nullptr, "chamfer_forward: workspace required (%zu bytes)",
-                  ptops_chamfer_forward_workspace_bytes(B, n, m));
+    PTOPS_REQUIRE(ws != nullptr, "chamfer_forward: workspace required (%zu bytes)", brute_workspace_bytes(B, n, m));
     if (((uintptr_t)ws & 7) != 0) {
       ptops::set_error("chamfer_forward: workspace must be 8-byte aligned");
       return PTOPS_EALIGN;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void chamfer_sort_kernel(const float* __restr
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < (N >> 1); t += 1024) {
-        const int i = 2 * j * (t / j) + (t % j);
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two: no division
         const int l = i + j;
         const unsigned long long a = keys[i], c = keys[l];
         const bool up = (i & k) == 0;
@@ -142,7 +142,8 @@ __device__ __forceinline__ int resolve_chunk(const float4* __restrict__ cb, int 
 template <int Q>
 __global__ __launch_bounds__(256) void chamfer_sweep_kernel(const float4* __restrict__ qs, int nq, int nqp,
                                                             const float4* __restrict__ cs, int ncp,
-                                                            float* __restrict__ dist, int32_t* __restrict__ idx) {
+                                                            float* __restrict__ dist, int32_t* __restrict__ idx,
+                                                            unsigned long long* __restrict__ stats) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_base = (blockIdx.x * 4 + wave) * (64 * Q);
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void chamfer_sweep_kernel(const float4* __rest
   }
   int cR = min(lo / kCH, nch - 1), cL = cR - 1;
   bool moreR = true, moreL = cL >= 0;
+  const int entry = cR;
 
   // One chunk (16 candidates at sorted position c*16): brute-force body + tie bookkeeping.
   auto do_chunk = [&](int c) {
@@ -264,6 +266,11 @@ __global__ __launch_bounds__(256) void chamfer_sweep_kernel(const float4* __rest
     }
   }
 
+  // pruning statistics for the caller's path selection: chunks this wave evaluated / chunks in total
+  if (stats != nullptr && lane == 0) {
+    atomicAdd(&stats[0], (unsigned long long)((cR - entry) + (entry - 1 - cL)));
+    atomicAdd(&stats[1], (unsigned long long)nch);
+  }
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
     if (qorig[i] < 0) continue;
@@ -299,13 +306,13 @@ static int ptops_sweep_q_override() {
 
 template <int Q>
 void launch_sweep(const float4* qs, int nq, int nqp, const float4* cs, int ncp, int B, float* dist,
-                  int32_t* idx, hipStream_t stream) {
+                  int32_t* idx, unsigned long long* stats, hipStream_t stream) {
   dim3 grid(ptops::ceil_div(nq, 256 * Q), B);
-  hipLaunchKernelGGL(chamfer_sweep_kernel<Q>, grid, dim3(256), 0, stream, qs, nq, nqp, cs, ncp, dist, idx);
+  hipLaunchKernelGGL(chamfer_sweep_kernel<Q>, grid, dim3(256), 0, stream, qs, nq, nqp, cs, ncp, dist, idx, stats);
 }
 
 int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
-            int32_t* idx1, int32_t* idx2, void* workspace, hipStream_t stream) {
+            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, hipStream_t stream) {
   const int np = pad16(n), mp = pad16(m);
   float4* s1 = reinterpret_cast<float4*>(workspace);
   float4* s2 = s1 + (size_t)B * np;
@@ -318,9 +325,9 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   hipLaunchKernelGGL(chamfer_sort_kernel, dim3(2 * B), dim3(1024), lds, stream, xyz1, n, np, s1, xyz2, m, mp, s2, B);
   auto sweep = [&](const float4* qs, int nq, int nqp, const float4* cs, int ncp, float* d, int32_t* id) {
     const int q = ptops_sweep_q_override() > 0 ? ptops_sweep_q_override() : (nq >= 8192 ? 4 : (nq >= 2048 ? 2 : 1));
-    if (q == 4) launch_sweep<4>(qs, nq, nqp, cs, ncp, B, d, id, stream);
-    else if (q == 2) launch_sweep<2>(qs, nq, nqp, cs, ncp, B, d, id, stream);
-    else launch_sweep<1>(qs, nq, nqp, cs, ncp, B, d, id, stream);
+    if (q == 4) launch_sweep<4>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
+    else if (q == 2) launch_sweep<2>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
+    else launch_sweep<1>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
   };
   sweep(s1, n, np, s2, mp, dist1, idx1);
   sweep(s2, m, mp, s1, np, dist2, idx2);

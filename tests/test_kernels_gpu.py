@@ -57,12 +57,16 @@ CHAMFER_CASES = [
 def test_chamfer_forward_bit_exact(native, ref, B, n, m, kind):
     rng = np.random.default_rng(B * 1000003 + n * 101 + m)
     a, b = _cloud(rng, B, n, kind), _cloud(rng, B, m, kind)
-    d1, d2, i1, i2 = native.chamfer_forward(_t(a), _t(b))
     r1, r2, j1, j2 = ref.chamfer_forward(a, b)
-    assert np.array_equal(d1.cpu().numpy().view(np.uint32), r1.view(np.uint32))
-    assert np.array_equal(d2.cpu().numpy().view(np.uint32), r2.view(np.uint32))
-    assert np.array_equal(i1.cpu().numpy(), j1)
-    assert np.array_equal(i2.cpu().numpy(), j2)
+    algos = [native.CHAMFER_BRUTE, native.CHAMFER_AUTO]
+    if native.load().ptops_chamfer_sweep_available(B, n, m):
+        algos.append(native.CHAMFER_SWEEP)
+    for algo in algos:   # every algorithm must reproduce the oracle bit for bit
+        d1, d2, i1, i2 = native.chamfer_forward(_t(a), _t(b), algorithm=algo)
+        assert np.array_equal(d1.cpu().numpy().view(np.uint32), r1.view(np.uint32)), algo
+        assert np.array_equal(d2.cpu().numpy().view(np.uint32), r2.view(np.uint32)), algo
+        assert np.array_equal(i1.cpu().numpy(), j1), algo
+        assert np.array_equal(i2.cpu().numpy(), j2), algo
 
 
 def test_chamfer_mixed_kinds(native, ref):
@@ -71,10 +75,33 @@ def test_chamfer_mixed_kinds(native, ref):
     for ka, kb, n, m in (("uniform", "clusters", 16384, 16384), ("lattice", "uniform", 4096, 8192),
                          ("clusters", "lattice", 5000, 4500)):
         a, b = _cloud(rng, 2, n, ka), _cloud(rng, 2, m, kb)
-        got = native.chamfer_forward(_t(a), _t(b))
         want = ref.chamfer_forward(a, b)
-        for g, w in zip(got, want):
-            assert np.array_equal(g.cpu().numpy(), w), (ka, kb)
+        for algo in (native.CHAMFER_SWEEP, native.CHAMFER_BRUTE):
+            got = native.chamfer_forward(_t(a), _t(b), algorithm=algo)
+            for g, w in zip(got, want):
+                assert np.array_equal(g.cpu().numpy(), w), (ka, kb, algo)
+
+
+def test_chamfer_adaptive_policy(native):
+    """The adaptive choice never changes results and backs off to brute force on unprunable input."""
+    native._chamfer_policy.state.clear()
+    gt = torch.rand(4, 8192, 3, device="cuda") - 0.5
+    blob = (torch.randn(4, 8192, 3, device="cuda") * 1e-3)           # everything in one tiny cluster
+    ref_out = native.chamfer_forward(blob, gt, algorithm=native.CHAMFER_BRUTE)
+    modes = []
+    for _ in range(6):
+        out = native.chamfer_forward(blob, gt)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, ref_out))
+        st = native._chamfer_policy.state[(0, 4, 8192, 8192)]
+        modes.append(st["brute_left"])
+    assert max(modes) > 0                                            # it switched to brute force
+    native._chamfer_policy.state.clear()
+    near = gt + torch.randn_like(gt) * 0.005                          # prediction close to the target
+    for _ in range(6):
+        native.chamfer_forward(near, gt)
+        torch.cuda.synchronize()
+    assert native._chamfer_policy.state[(0, 4, 8192, 8192)]["brute_left"] == 0   # the sweep is kept
 
 
 def test_chamfer_identity(native):
