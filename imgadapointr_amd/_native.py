@@ -35,7 +35,7 @@ def _declare(lib):
         "ptops_last_error": (ctypes.c_char_p, []),
         "ptops_chamfer_forward_workspace_bytes": (c_size, [c_int] * 3),
         "ptops_chamfer_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, P]),
-        "ptops_chamfer_forward_ex": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+        "ptops_chamfer_forward_ex": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P]),
         "ptops_chamfer_sweep_available": (c_int, [c_int] * 3),
         "ptops_chamfer_backward": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P]),
         "ptops_furthest_point_sample": (c_int, [P, c_int, c_int, c_int, P, P]),
@@ -140,39 +140,45 @@ CHAMFER_AUTO, CHAMFER_BRUTE, CHAMFER_SWEEP = 0, 1, 2
 
 
 class _ChamferPolicy:
-    """Per-shape choice between the two exact Chamfer algorithms (bit-identical results).
+    """Per-shape, per-direction choice between the two exact Chamfer algorithms (bit-identical results).
 
-    The pruned sweep is 3x faster than brute force when nearest neighbours are close (trained
-    predictions, well-spread clouds) and ~15 % slower when they are not (e.g. a randomly initialised
-    model whose prediction collapses to a few clusters).  Every sweep launch accumulates
-    {chunks evaluated, chunks a brute force would evaluate} on the device; the pair is copied to pinned
-    host memory without synchronising and looked at on a LATER call.  If more than `threshold` of the
-    pairs still had to be evaluated, the next `hold` calls of that shape use brute force, then the sweep
-    is probed again."""
-    threshold = 0.6
+    The pruned sweep is ~3x faster than brute force when nearest neighbours are close (trained
+    predictions, well-spread clouds) and slower when they are not (e.g. uniform queries against a
+    prediction collapsed into a few clusters).  Every swept direction accumulates {chunks evaluated,
+    chunks a brute force would evaluate} on the device; the counters are copied to pinned host memory
+    without synchronising and looked at on a LATER call.  If more than `threshold` of the pairs still
+    had to be evaluated, that direction uses brute force for the next `hold` calls of the shape, then
+    the sweep is probed again."""
+    threshold = 0.5
     hold = 50
 
     def __init__(self):
         self.state = {}
 
     def choose(self, key):
-        st = self.state.setdefault(key, dict(brute_left=0, pending=None))
+        st = self.state.setdefault(key, dict(brute_left=[0, 0], pending=None))
         pend = st["pending"]
         if pend is not None and pend[1].query():
-            ev, tot = pend[0][0].item(), pend[0][1].item()
+            vals = pend[0].tolist()
             st["pending"] = None
-            if tot > 0 and ev / tot > self.threshold:
-                st["brute_left"] = self.hold
-        if st["brute_left"] > 0:
-            st["brute_left"] -= 1
-            return CHAMFER_BRUTE, None
-        return CHAMFER_SWEEP, st
+            for d in range(2):
+                ev, tot = vals[2 * d], vals[2 * d + 1]
+                if tot > 0 and ev / tot > self.threshold:
+                    st["brute_left"][d] = self.hold
+        algos = []
+        for d in range(2):
+            if st["brute_left"][d] > 0:
+                st["brute_left"][d] -= 1
+                algos.append(CHAMFER_BRUTE)
+            else:
+                algos.append(CHAMFER_SWEEP)
+        return algos, st
 
     @staticmethod
     def record(st, stats_dev):
         if st is None or st["pending"] is not None:
             return
-        host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        host = torch.empty(4, dtype=torch.int64, pin_memory=True)
         host.copy_(stats_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -184,7 +190,8 @@ _chamfer_policy = _ChamferPolicy()
 
 def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
     """chamfer.forward (extensions/chamfer_dist/chamfer_cuda.cpp:22-25).  `algorithm`: CHAMFER_AUTO
-    (adaptive, see _ChamferPolicy), CHAMFER_BRUTE or CHAMFER_SWEEP — the results are identical."""
+    (adaptive per direction, see _ChamferPolicy), CHAMFER_BRUTE, CHAMFER_SWEEP, or a pair of those for
+    (xyz1->xyz2, xyz2->xyz1) — the results are identical."""
     if _test_backend is not None:
         return _test_backend.chamfer_forward(xyz1, xyz2)
     _check(xyz1, "xyz1", torch.float32, 3)
@@ -195,23 +202,24 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
     if c != 3 or c2 != 3 or B != B2:
         raise ValueError(f"chamfer_forward: expected [B,n,3] and [B,m,3], got {tuple(xyz1.shape)} {tuple(xyz2.shape)}")
     lib = load()
+    algos = list(algorithm) if isinstance(algorithm, (tuple, list)) else [algorithm, algorithm]
     with torch.cuda.device(dev):
         dist1 = torch.empty((B, n), dtype=torch.float32, device=dev)
         dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
         idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
         idx2 = torch.empty((B, m), dtype=torch.int32, device=dev)
         wsb = lib.ptops_chamfer_forward_workspace_bytes(B, n, m)
-        ws = torch.empty((wsb // 8,), dtype=torch.int64, device=dev) if wsb else None
+        ws = torch.empty(((wsb + 15) // 16 * 2,), dtype=torch.int64, device=dev) if wsb else None
         stats = st = None
         if lib.ptops_chamfer_sweep_available(B, n, m):
-            if algorithm == CHAMFER_AUTO:
-                algorithm, st = _chamfer_policy.choose((dev.index, B, n, m))
-            if algorithm == CHAMFER_SWEEP and st is not None:
-                stats = torch.zeros(2, dtype=torch.int64, device=dev)
-        elif algorithm == CHAMFER_AUTO:
-            algorithm = CHAMFER_BRUTE
+            if algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
+                algos, st = _chamfer_policy.choose((dev.index, B, n, m))
+                if CHAMFER_SWEEP in algos and st["pending"] is None:
+                    stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        else:
+            algos = [CHAMFER_BRUTE if a == CHAMFER_AUTO else a for a in algos]
         _call("ptops_chamfer_forward_ex", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist1), _ptr(dist2),
-              _ptr(idx1), _ptr(idx2), _ptr(ws) if ws is not None else None, int(algorithm),
+              _ptr(idx1), _ptr(idx2), _ptr(ws) if ws is not None else None, int(algos[0]), int(algos[1]),
               _ptr(stats) if stats is not None else None, _stream(xyz1))
         if stats is not None:
             _chamfer_policy.record(st, stats)

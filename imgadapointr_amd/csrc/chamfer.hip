@@ -296,10 +296,8 @@ static size_t brute_workspace_bytes(int B, int n, int m) {
 
 PTOPS_API size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
-  // large enough for either algorithm, so that a caller may switch between them per call
-  const size_t a = brute_workspace_bytes(B, n, m);
-  const size_t b = use_sweep(B, n, m) ? ptops_sweep::workspace_bytes(B, n, m) : 0;
-  return a > b ? a : b;
+  // room for both algorithms at once: the two directions of one call may use different ones
+  return brute_workspace_bytes(B, n, m) + (use_sweep(B, n, m) ? ptops_sweep::workspace_bytes(B, n, m) : 0);
 }
 
 PTOPS_API int ptops_chamfer_sweep_available(int B, int n, int m) {
@@ -308,60 +306,39 @@ PTOPS_API int ptops_chamfer_sweep_available(int B, int n, int m) {
 
 PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1,
                                        float* dist2, int32_t* idx1, int32_t* idx2, void* workspace,
-                                       int algorithm, unsigned long long* stats, void* stream_);
+                                       int algorithm1, int algorithm2, unsigned long long* stats, void* stream_);
 
 PTOPS_API int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, int m,
                                     float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
                                     void* workspace, void* stream_) {
   return ptops_chamfer_forward_ex(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, PTOPS_CHAMFER_AUTO,
-                                  nullptr, stream_);
+                                  PTOPS_CHAMFER_AUTO, nullptr, stream_);
 }
 
-PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1,
-                                       float* dist2, int32_t* idx1, int32_t* idx2, void* workspace,
-                                       int algorithm, unsigned long long* stats, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  PTOPS_REQUIRE(algorithm == PTOPS_CHAMFER_AUTO || algorithm == PTOPS_CHAMFER_BRUTE || algorithm == PTOPS_CHAMFER_SWEEP,
-                "chamfer_forward: unknown algorithm %d", algorithm);
-  PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_forward: negative size");
-  if (B == 0) return PTOPS_OK;
-  PTOPS_REQUIRE(dist1 && dist2 && idx1 && idx2, "chamfer_forward: null output");
-  if (n == 0 || m == 0) {  // the reference returns its zero-initialised outputs (chamfer.cu:152-157)
-    if (n) (void)hipMemsetAsync(dist1, 0, sizeof(float) * (size_t)B * n, stream), (void)hipMemsetAsync(idx1, 0, sizeof(int32_t) * (size_t)B * n, stream);
-    if (m) (void)hipMemsetAsync(dist2, 0, sizeof(float) * (size_t)B * m, stream), (void)hipMemsetAsync(idx2, 0, sizeof(int32_t) * (size_t)B * m, stream);
-    return ptops::check_launch("chamfer_forward(memset)");
-  }
-  PTOPS_REQUIRE(xyz1 && xyz2, "chamfer_forward: null input");
-  PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
-                "chamfer_forward: B*n*3 must fit int32");
-  PTOPS_REQUIRE(algorithm != PTOPS_CHAMFER_SWEEP || use_sweep(B, n, m),
-                "chamfer_forward: the sweep needs both clouds within [4096, 16384] points (n=%d m=%d)", n, m);
-  if (algorithm != PTOPS_CHAMFER_BRUTE && use_sweep(B, n, m)) {
-    PTOPS_REQUIRE(workspace != nullptr, "chamfer_forward: workspace required (%zu bytes)",
-                  ptops_sweep::workspace_bytes(B, n, m));
-    if (((uintptr_t)workspace & 15) != 0) {
-      ptops::set_error("chamfer_forward: workspace must be 16-byte aligned");
-      return PTOPS_EALIGN;
-    }
-    return ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, workspace, stats, stream);
-  }
+// Brute force for the directions in dirmask (bit 0: xyz1 -> xyz2, bit 1: xyz2 -> xyz1).
+static int brute_forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
+                         int32_t* idx1, int32_t* idx2, unsigned long long* ws, int dirmask, hipStream_t stream) {
   const Plan p = make_plan(B, n, m);
-  unsigned long long* ws = (unsigned long long*)workspace;
-  if (p.need_ws) {
+  const bool on[2] = {(dirmask & 1) != 0, (dirmask & 2) != 0};
+  const bool split[2] = {on[0] && p.splits[0] > 1, on[1] && p.splits[1] > 1};
+  if (split[0] || split[1]) {
     PTOPS_REQUIRE(ws != nullptr, "chamfer_forward: workspace required (%zu bytes)", brute_workspace_bytes(B, n, m));
     if (((uintptr_t)ws & 7) != 0) {
       ptops::set_error("chamfer_forward: workspace must be 8-byte aligned");
       return PTOPS_EALIGN;
     }
-    (void)hipMemsetAsync(ws, 0xFF, sizeof(unsigned long long) * (size_t)B * ((size_t)n + m), stream);
+    if (split[0]) (void)hipMemsetAsync(ws, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream);
+    if (split[1]) (void)hipMemsetAsync(ws + (size_t)B * n, 0xFF, sizeof(unsigned long long) * (size_t)B * m, stream);
   }
   Args a;
+  const long long blocks0 = on[0] ? (long long)B * p.qtiles[0] * p.splits[0] : 0;
+  const long long blocks1 = on[1] ? (long long)B * p.qtiles[1] * p.splits[1] : 0;
   a.d[0] = Dir{xyz1, xyz2, dist1, idx1, ws, n, m, p.qtiles[0], p.splits[0], p.cps[0], 0};
-  const long long blocks0 = (long long)B * p.qtiles[0] * p.splits[0];
   a.d[1] = Dir{xyz2, xyz1, dist2, idx2, ws ? ws + (size_t)B * n : nullptr, m, n, p.qtiles[1],
                p.splits[1], p.cps[1], (int)blocks0};
-  const long long blocks = blocks0 + (long long)B * p.qtiles[1] * p.splits[1];
+  const long long blocks = blocks0 + blocks1;
   PTOPS_REQUIRE(blocks < (1LL << 31), "chamfer_forward: grid too large");
+  if (blocks == 0) return PTOPS_OK;
   dim3 grid((unsigned)blocks), block(kTPB);
   switch (p.Q * 2 + (p.pk ? 1 : 0)) {
     case 17: hipLaunchKernelGGL((chamfer_nn_kernel<8, true>), grid, block, 0, stream, a); break;
@@ -374,18 +351,59 @@ PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int
   }
   int rc = ptops::check_launch("chamfer_nn_kernel");
   if (rc != PTOPS_OK) return rc;
-  if (p.need_ws) {
-    // Unpack only the directions that were split; unsplit ones wrote dist/idx directly.
-    for (int d = 0; d < 2; ++d) {
-      if (p.splits[d] == 1) continue;
-      const long long total = (long long)B * (d ? m : n);
-      const int g = (int)(ptops::ceil_div_ll(total, 256) < 2048 ? ptops::ceil_div_ll(total, 256) : 2048);
-      hipLaunchKernelGGL(chamfer_unpack_kernel, dim3(g), dim3(256), 0, stream,
-                         d ? ws + (size_t)B * n : ws, d ? dist2 : dist1, d ? idx2 : idx1, total);
-    }
+  for (int d = 0; d < 2; ++d) {  // unpack only the directions that were split
+    if (!split[d]) continue;
+    const long long total = (long long)B * (d ? m : n);
+    const int g = (int)(ptops::ceil_div_ll(total, 256) < 2048 ? ptops::ceil_div_ll(total, 256) : 2048);
+    hipLaunchKernelGGL(chamfer_unpack_kernel, dim3(g), dim3(256), 0, stream, d ? ws + (size_t)B * n : ws,
+                       d ? dist2 : dist1, d ? idx2 : idx1, total);
     rc = ptops::check_launch("chamfer_unpack_kernel");
   }
   return rc;
+}
+
+PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1,
+                                       float* dist2, int32_t* idx1, int32_t* idx2, void* workspace,
+                                       int algorithm1, int algorithm2, unsigned long long* stats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int algo[2] = {algorithm1, algorithm2};
+  for (int d = 0; d < 2; ++d)
+    PTOPS_REQUIRE(algo[d] == PTOPS_CHAMFER_AUTO || algo[d] == PTOPS_CHAMFER_BRUTE || algo[d] == PTOPS_CHAMFER_SWEEP,
+                  "chamfer_forward: unknown algorithm %d", algo[d]);
+  PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_forward: negative size");
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(dist1 && dist2 && idx1 && idx2, "chamfer_forward: null output");
+  if (n == 0 || m == 0) {  // the reference returns its zero-initialised outputs (chamfer.cu:152-157)
+    if (n) (void)hipMemsetAsync(dist1, 0, sizeof(float) * (size_t)B * n, stream), (void)hipMemsetAsync(idx1, 0, sizeof(int32_t) * (size_t)B * n, stream);
+    if (m) (void)hipMemsetAsync(dist2, 0, sizeof(float) * (size_t)B * m, stream), (void)hipMemsetAsync(idx2, 0, sizeof(int32_t) * (size_t)B * m, stream);
+    return ptops::check_launch("chamfer_forward(memset)");
+  }
+  PTOPS_REQUIRE(xyz1 && xyz2, "chamfer_forward: null input");
+  PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
+                "chamfer_forward: B*n*3 must fit int32");
+  const bool can_sweep = use_sweep(B, n, m);
+  int sweep_mask = 0;
+  for (int d = 0; d < 2; ++d) {
+    PTOPS_REQUIRE(algo[d] != PTOPS_CHAMFER_SWEEP || can_sweep,
+                  "chamfer_forward: the sweep needs both clouds within [4096, 16384] points (n=%d m=%d)", n, m);
+    if (can_sweep && algo[d] != PTOPS_CHAMFER_BRUTE) sweep_mask |= 1 << d;
+  }
+  // workspace layout: [sorted clouds for the sweep | packed minima for split brute force]
+  char* wsp = (char*)workspace;
+  const size_t sweep_bytes = can_sweep ? ptops_sweep::workspace_bytes(B, n, m) : 0;
+  if (sweep_mask) {
+    PTOPS_REQUIRE(wsp != nullptr, "chamfer_forward: workspace required (%zu bytes)",
+                  ptops_chamfer_forward_workspace_bytes(B, n, m));
+    if (((uintptr_t)wsp & 15) != 0) {
+      ptops::set_error("chamfer_forward: workspace must be 16-byte aligned");
+      return PTOPS_EALIGN;
+    }
+    int rc = ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, wsp, stats, sweep_mask, stream);
+    if (rc != PTOPS_OK) return rc;
+  }
+  if (sweep_mask == 3) return PTOPS_OK;
+  return brute_forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2,
+                       wsp ? (unsigned long long*)(wsp + sweep_bytes) : nullptr, 3 & ~sweep_mask, stream);
 }
 
 PTOPS_API int ptops_chamfer_backward(const float* xyz1, const float* xyz2, const int32_t* idx1,

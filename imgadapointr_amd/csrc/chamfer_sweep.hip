@@ -311,8 +311,10 @@ void launch_sweep(const float4* qs, int nq, int nqp, const float4* cs, int ncp, 
   hipLaunchKernelGGL(chamfer_sweep_kernel<Q>, grid, dim3(256), 0, stream, qs, nq, nqp, cs, ncp, dist, idx, stats);
 }
 
+// dirmask bit 0: sweep xyz1 -> xyz2 (dist1/idx1), bit 1: xyz2 -> xyz1.  Both clouds are sorted either way.
 int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
-            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, hipStream_t stream) {
+            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, int dirmask,
+            hipStream_t stream) {
   const int np = pad16(n), mp = pad16(m);
   float4* s1 = reinterpret_cast<float4*>(workspace);
   float4* s2 = s1 + (size_t)B * np;
@@ -323,14 +325,15 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chamfer_sort_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kMaxSort);
   hipLaunchKernelGGL(chamfer_sort_kernel, dim3(2 * B), dim3(1024), lds, stream, xyz1, n, np, s1, xyz2, m, mp, s2, B);
-  auto sweep = [&](const float4* qs, int nq, int nqp, const float4* cs, int ncp, float* d, int32_t* id) {
+  auto sweep = [&](const float4* qs, int nq, int nqp, const float4* cs, int ncp, float* d, int32_t* id,
+                   unsigned long long* stats) {
     const int q = ptops_sweep_q_override() > 0 ? ptops_sweep_q_override() : (nq >= 8192 ? 4 : (nq >= 2048 ? 2 : 1));
     if (q == 4) launch_sweep<4>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
     else if (q == 2) launch_sweep<2>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
     else launch_sweep<1>(qs, nq, nqp, cs, ncp, B, d, id, stats, stream);
   };
-  sweep(s1, n, np, s2, mp, dist1, idx1);
-  sweep(s2, m, mp, s1, np, dist2, idx2);
+  if (dirmask & 1) sweep(s1, n, np, s2, mp, dist1, idx1, stats);
+  if (dirmask & 2) sweep(s2, m, mp, s1, np, dist2, idx2, stats ? stats + 2 : nullptr);
   return ptops::check_launch("chamfer_sweep");
 }
 

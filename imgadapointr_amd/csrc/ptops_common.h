@@ -35,7 +35,8 @@ namespace ptops_sweep {
 bool eligible(int B, int n, int m);
 size_t workspace_bytes(int B, int n, int m);
 int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
-            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, hipStream_t stream);
+            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, int dirmask,
+            hipStream_t stream);
 }  // namespace ptops_sweep
 
 #define PTOPS_REQUIRE(cond, ...)        \

@@ -47,21 +47,23 @@ int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, in
                           float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
                           void* workspace, void* stream);
 
-/* Same operator with an explicit algorithm.  Both algorithms return bit-identical results:
+/* Same operator with an explicit algorithm per direction (algorithm1: xyz1 -> xyz2, dist1/idx1;
+ * algorithm2: xyz2 -> xyz1).  Both algorithms return bit-identical results:
  *   PTOPS_CHAMFER_BRUTE  every pair is evaluated (VALU-issue bound);
  *   PTOPS_CHAMFER_SWEEP  clouds are sorted by x and every query tile sweeps outwards until no farther
  *                        candidate can win or tie (exact pruning; needs ptops_chamfer_sweep_available);
  *   PTOPS_CHAMFER_AUTO   the sweep whenever it is available.
- * stats (optional, 2 x u64, device memory, caller-zeroed): the sweep adds {16-candidate chunks evaluated,
- * chunks a brute force would evaluate}, so that a caller can steer the choice for the following calls. */
+ * stats (optional, 4 x u64, device memory, caller-zeroed): a swept direction d adds {16-candidate chunks
+ * evaluated, chunks a brute force would evaluate} to stats[2d], stats[2d+1], so that a caller can steer the
+ * choice for the following calls. */
 #define PTOPS_CHAMFER_AUTO 0
 #define PTOPS_CHAMFER_BRUTE 1
 #define PTOPS_CHAMFER_SWEEP 2
 int ptops_chamfer_sweep_available(int B, int n, int m);
 int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m,
                              float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
-                             void* workspace, int algorithm, unsigned long long* stats,
-                             void* stream);
+                             void* workspace, int algorithm1, int algorithm2,
+                             unsigned long long* stats, void* stream);
 
 /* Replaces chamfer.backward (extensions/chamfer_dist/chamfer_cuda.cpp:27-34,
  * kernel extensions/chamfer_dist/chamfer.cu:173-229).

@@ -27,7 +27,10 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_query_is_pure_host_code():
     from imgadapointr_amd import _native
     lib = _native.load()
-    assert lib.ptops_chamfer_forward_workspace_bytes(32, 16384, 16384) in (0, 8 * 32 * 32768)
+    # sorted float4 copies of both clouds for the sweep + packed minima for the split brute force
+    assert lib.ptops_chamfer_sweep_available(32, 16384, 16384) == 1
+    assert lib.ptops_chamfer_forward_workspace_bytes(32, 16384, 16384) == 16 * 32 * 32768 + 8 * 32 * 32768
+    assert lib.ptops_chamfer_sweep_available(32, 512, 16384) == 0
     assert lib.ptops_chamfer_forward_workspace_bytes(32, 512, 16384) == 8 * 32 * (512 + 16384)
     assert lib.ptops_chamfer_forward_workspace_bytes(0, 10, 10) == 0
 

@@ -60,7 +60,8 @@ def test_chamfer_forward_bit_exact(native, ref, B, n, m, kind):
     r1, r2, j1, j2 = ref.chamfer_forward(a, b)
     algos = [native.CHAMFER_BRUTE, native.CHAMFER_AUTO]
     if native.load().ptops_chamfer_sweep_available(B, n, m):
-        algos.append(native.CHAMFER_SWEEP)
+        algos += [native.CHAMFER_SWEEP, (native.CHAMFER_SWEEP, native.CHAMFER_BRUTE),
+                  (native.CHAMFER_BRUTE, native.CHAMFER_SWEEP)]
     for algo in algos:   # every algorithm must reproduce the oracle bit for bit
         d1, d2, i1, i2 = native.chamfer_forward(_t(a), _t(b), algorithm=algo)
         assert np.array_equal(d1.cpu().numpy().view(np.uint32), r1.view(np.uint32)), algo
@@ -83,25 +84,27 @@ def test_chamfer_mixed_kinds(native, ref):
 
 
 def test_chamfer_adaptive_policy(native):
-    """The adaptive choice never changes results and backs off to brute force on unprunable input."""
+    """The adaptive choice never changes results; a direction that cannot prune backs off to brute force."""
+    key = (0, 4, 8192, 8192)
     native._chamfer_policy.state.clear()
     gt = torch.rand(4, 8192, 3, device="cuda") - 0.5
-    blob = (torch.randn(4, 8192, 3, device="cuda") * 1e-3)           # everything in one tiny cluster
+    blob = (torch.randn(4, 8192, 3, device="cuda") * 1e-3)           # the whole cloud in one tiny cluster
     ref_out = native.chamfer_forward(blob, gt, algorithm=native.CHAMFER_BRUTE)
-    modes = []
+    backed_off = [0, 0]
     for _ in range(6):
         out = native.chamfer_forward(blob, gt)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(out, ref_out))
-        st = native._chamfer_policy.state[(0, 4, 8192, 8192)]
-        modes.append(st["brute_left"])
-    assert max(modes) > 0                                            # it switched to brute force
+        for d in range(2):
+            backed_off[d] = max(backed_off[d], native._chamfer_policy.state[key]["brute_left"][d])
+    # uniform queries against one cluster (direction 2) cannot prune; cluster queries against a uniform cloud can
+    assert backed_off[1] > 0 and backed_off[0] == 0, backed_off
     native._chamfer_policy.state.clear()
     near = gt + torch.randn_like(gt) * 0.005                          # prediction close to the target
     for _ in range(6):
         native.chamfer_forward(near, gt)
         torch.cuda.synchronize()
-    assert native._chamfer_policy.state[(0, 4, 8192, 8192)]["brute_left"] == 0   # the sweep is kept
+    assert native._chamfer_policy.state[key]["brute_left"] == [0, 0]  # both directions keep sweeping
 
 
 def test_chamfer_identity(native):
