@@ -50,6 +50,8 @@ def _declare(lib):
         "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_emd_forward": (c_int, [P, P, c_int, c_int, c_int] + [P] * 12 + [ctypes.c_float, c_int, P]),
         "ptops_emd_backward": (c_int, [P] * 5 + [c_int] * 3 + [P]),
+        "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
+        "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
     }
     for name, (res, args) in sig.items():
@@ -66,7 +68,7 @@ EXPORTS = (
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
-    "ptops_attention_forward",
+    "ptops_attention_forward", "ptops_colsum_workspace_bytes", "ptops_colsum",
 )
 
 
@@ -488,3 +490,16 @@ def attention_forward(q, k, v, split_q, limit_k, scale):
         _call("ptops_attention_forward", _ptr(q), _ptr(k), _ptr(v), B, H, Nq, Nk, qs, ks, vs, int(split_q),
               int(limit_k), ctypes.c_float(float(scale)), _ptr(out), _ptr(lse), _stream(q))
     return out, lse
+
+
+def colsum(x):
+    """x [M,N] float32 contiguous (N % 4 == 0) -> column sums [N] (deterministic)."""
+    if _test_backend is not None:
+        return x.sum(0)
+    _check(x, "x", torch.float32, 2)
+    M, N = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((max(load().ptops_colsum_workspace_bytes(M, N) // 4, 4),), dtype=torch.float32, device=x.device)
+        _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), _stream(x))
+    return out

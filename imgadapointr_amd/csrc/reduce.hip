@@ -1,0 +1,73 @@
+// Column sums of a row-major fp32 matrix: out[n] = sum_m x[m, n]  (bias gradients of the dense layers).
+//
+// PyTorch's generic reduce kernel runs this shape (M = 8192..18432 rows, N = 96..1152 columns) on 2-5
+// workgroups at ~1.4 TB/s; it is a pure streaming read, so it is laid out for the memory system instead:
+// 16 lanes x float4 cover 64 contiguous columns (256 B per row), 16 row-lanes per workgroup walk the
+// rows, the grid has (N/64) x S workgroups with S row slabs, each writing one partial row; a second
+// tiny launch adds the S partials in a fixed order (deterministic, no atomics).
+#include "ptops_common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 512;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int M, int N,
+                                                             float* __restrict__ partial) {
+  __shared__ float4 red[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = (blockIdx.x * 16 + cx) * 4;
+  const int r0 = blockIdx.y * kRowsPerBlock, r1 = min(M, r0 + kRowsPerBlock);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < N) {
+    for (int r = r0 + ry; r < r1; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * N + col);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    float4 s = red[0][cx];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) {
+      const float4 v = red[t][cx];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + col) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
+                                                           float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int t = 0; t < S; ++t) s += partial[(size_t)t * N + n];
+  out[n] = s;
+}
+
+}  // namespace
+
+PTOPS_API size_t ptops_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return sizeof(float) * (size_t)ptops::ceil_div(M, kRowsPerBlock) * N;
+}
+
+PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(M >= 0 && N >= 1, "colsum: bad size");
+  PTOPS_REQUIRE(out != nullptr, "colsum: null output");
+  if (M == 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, stream);
+    return ptops::check_launch("colsum(memset)");
+  }
+  PTOPS_REQUIRE(x && workspace, "colsum: null pointer");
+  PTOPS_REQUIRE(N % 4 == 0 && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0,
+                "colsum: N must be a multiple of 4 and pointers 16-byte aligned");
+  const int S = ptops::ceil_div(M, kRowsPerBlock);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ptops::ceil_div(N, 64), S), dim3(256), 0, stream, x, M, N,
+                     (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 256)), dim3(256), 0, stream,
+                     (const float*)workspace, S, N, out);
+  return ptops::check_launch("colsum");
+}

@@ -30,6 +30,14 @@ USE_SDPA = True
 USE_MFMA_ATTENTION = True
 _LN2 = 0.6931471805599453
 _bias_cache = {}
+_zero_cache = {}
+
+
+def _zero_i64(device):
+    z = _zero_cache.get(device)
+    if z is None:
+        z = _zero_cache[device] = torch.zeros((), dtype=torch.int64, device=device)
+    return z
 
 
 # Linear layers whose input is cat([per-cloud vector broadcast over tokens, per-token features]):
@@ -45,6 +53,43 @@ def linear_on_broadcast_concat(lin, g, x):
     G = g.size(-1)
     per_cloud = F.linear(g, lin.weight[:, :G], lin.bias)        # [B,O]
     return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
+
+
+class _LinearFn(torch.autograd.Function):
+    """F.linear whose bias gradient is libptops' streaming column sum (csrc/reduce.hip) instead of the
+    generic 2-5 workgroup reduction autograd would run; the three GEMMs are the ones autograd runs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        g2 = grad.reshape(-1, grad.size(-1))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = g2.t() @ x.reshape(-1, x.size(-1))
+        if ctx.needs_input_grad[2]:
+            gb = _native.colsum(g2.contiguous())
+        return gx, gw, gb
+
+
+FAST_BIAS_GRAD = True
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state-dict keys) with the bias-gradient reduction on libptops."""
+
+    def forward(self, x):
+        if (FAST_BIAS_GRAD and self.bias is not None and x.is_cuda and x.dtype == torch.float32
+                and self.out_features % 4 == 0 and torch.is_grad_enabled() and x.dim() >= 2
+                and x.numel() // x.size(-1) >= 2048 and _native.backend_for_testing() is None):
+            return _LinearFn.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
 
 
 # ------------------------------------------------------------------------------ functional
@@ -121,9 +166,9 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = Linear(in_features, hidden_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -160,11 +205,46 @@ class _MFMAAttention(torch.autograd.Function):
         bias = None
         if split_q > 0 and limit_k < Nk:
             bias = _block_bias(Nq, Nk, split_q, limit_k, q.device).expand(B, H, Nq, Nk)
-        zero = torch.zeros((), dtype=torch.int64, device=q.device)
+        zero = _zero_i64(q.device)   # philox seed / offset: unused without dropout
         gq, gk, gv, _ = torch.ops.aten._efficient_attention_backward(
             grad_out.contiguous(), q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), bias, out, None, None,
             Nq, Nk, lse2 * _LN2, 0.0, zero, zero, 0, False, scale=ctx.scale)
         return gq.transpose(1, 2), gk.transpose(1, 2), gv.transpose(1, 2), None, None, None
+
+
+class _MFMASelfAttention(torch.autograd.Function):
+    """Self attention on the PACKED projection qkv [B,N,3,h,64]: the backward asks
+    aten::_efficient_attention_backward for dq/dk/dv in one [B,N,3,h,64] allocation and returns it as the
+    gradient of qkv, so autograd does not have to zero-fill and scatter three slices per layer."""
+
+    @staticmethod
+    def forward(ctx, qkv, split_q, limit_k, scale):
+        q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+        out, lse2 = _native.attention_forward(q, k, v, split_q, limit_k, scale)
+        ctx.save_for_backward(qkv, out, lse2)
+        ctx.mask, ctx.scale = (split_q, limit_k), scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qkv, out, lse2 = ctx.saved_tensors
+        split_q, limit_k = ctx.mask
+        B, N, _, H, D = qkv.shape
+        q, k, v = qkv.unbind(2)                               # [B,N,h,d] views, the layout the op expects
+        bias = None
+        if split_q > 0 and limit_k < N:
+            bias = _block_bias(N, N, split_q, limit_k, qkv.device).expand(B, H, N, N)
+        zero = _zero_i64(qkv.device)
+        gq, gk, gv, _ = torch.ops.aten._efficient_attention_backward(
+            grad_out.contiguous(), q, k, v, bias, out, None, None, N, N, lse2 * _LN2, 0.0, zero, zero, 0, False,
+            scale=ctx.scale, shared_storage_dqdkdv=True)
+        packed_strides = (N * 3 * H * D, 3 * H * D, D, 1)
+        if (gq.stride() == packed_strides and gk.data_ptr() == gq.data_ptr() + 4 * H * D
+                and gv.data_ptr() == gq.data_ptr() + 8 * H * D):
+            g = torch.as_strided(gq, (B, N, 3, H, D), (N * 3 * H * D, 3 * H * D, H * D, D, 1))
+        else:                                                 # the op did not share storage: assemble
+            g = torch.stack([gq, gk, gv], dim=2)
+        return g, None, None, None
 
 
 def _attend(q, k, v, scale, mask, attn_drop, mask_split=None):
@@ -198,17 +278,24 @@ class Attention(nn.Module):
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x, mask=None, mask_split=None):
         """mask: [N,N], > 0 = blocked (reference semantics).  mask_split = (split_q, limit_k), optional:
         tells that `mask` is the block mask "queries < split_q do not see keys >= limit_k"."""
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        packed = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv = packed.permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
+        if (USE_MFMA_ATTENTION and (mask is None or mask_split is not None) and _native.backend_for_testing() is None
+                and (self.attn_drop.p == 0.0 or not self.training)):
+            split_q, limit_k = mask_split if mask_split is not None else (0, N)
+            if _native.attention_supported(q, k, split_q, limit_k):
+                x = _MFMASelfAttention.apply(packed, split_q, limit_k, self.scale).reshape(B, N, C)
+                return self.proj_drop(self.proj(x))
         if mask is not None:
             mask = mask > 0  # 1 = blocked
         x = _attend(q, k, v, self.scale, mask, self.attn_drop, mask_split).reshape(B, N, C)
@@ -225,11 +312,11 @@ class CrossAttention(nn.Module):
         self.out_dim = out_dim
         head_dim = out_dim // num_heads
         self.scale = qk_scale or head_dim ** -0.5
-        self.q_map = nn.Linear(dim, out_dim, bias=qkv_bias)
-        self.k_map = nn.Linear(dim, out_dim, bias=qkv_bias)
-        self.v_map = nn.Linear(dim, out_dim, bias=qkv_bias)
+        self.q_map = Linear(dim, out_dim, bias=qkv_bias)
+        self.k_map = Linear(dim, out_dim, bias=qkv_bias)
+        self.v_map = Linear(dim, out_dim, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(out_dim, out_dim)
+        self.proj = Linear(out_dim, out_dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, q, v):

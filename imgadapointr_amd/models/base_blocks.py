@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _native
 from ..pointnet2_ops import pointnet2_utils
-from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerScale, Mlp,
+from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerScale, Linear, Mlp,
                                 knn_idx, linear_on_broadcast_concat)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
@@ -93,7 +93,7 @@ class SelfAttnBlockApi(nn.Module):
                 self.local_attn = _local_module(token, dim, k)
         if self.attn is not None and self.local_attn is not None:
             if combine_style == 'concat':
-                self.merge_map = nn.Linear(dim * 2, dim)
+                self.merge_map = Linear(dim * 2, dim)
             else:
                 self.norm3 = norm_layer(dim)
                 self.ls3 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
@@ -152,7 +152,7 @@ class CrossAttnBlockApi(nn.Module):
                 self.local_self_attn = _local_module(token, dim, k)
         if self.self_attn is not None and self.local_self_attn is not None:
             if self_attn_combine_style == 'concat':
-                self.self_attn_merge_map = nn.Linear(dim * 2, dim)
+                self.self_attn_merge_map = Linear(dim * 2, dim)
             else:
                 self.norm3 = norm_layer(dim)
                 self.ls3 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
@@ -181,22 +181,29 @@ class CrossAttnBlockApi(nn.Module):
                 self.local_cross_attn = _local_module(token, dim, k)
         if self.cross_attn is not None and self.local_cross_attn is not None:
             if cross_attn_combine_style == 'concat':
-                self.cross_attn_merge_map = nn.Linear(dim * 2, dim)
+                self.cross_attn_merge_map = Linear(dim * 2, dim)
             else:
                 self.norm_q_2 = norm_layer(dim)
                 self.norm_v_2 = norm_layer(dim)
                 self.ls5 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
                 self.drop_path5 = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward(self, q, v, q_pos, v_pos, self_attn_idx=None, cross_attn_idx=None, denoise_length=None):
-        # Denoise mask (base_blocks.py:224-229): 1 = blocked; the real queries (rows [:-dl]) may not
-        # attend to the denoise tokens (columns [-dl:]); denoise tokens see everything.
+    @staticmethod
+    def denoise_mask(n, denoise_length, device):
+        """[n,n] mask, 1 = blocked (base_blocks.py:224-229): the real queries (rows [:-dl]) may not attend
+        to the denoise tokens (columns [-dl:]); denoise tokens see everything."""
+        mask = torch.zeros(n, n, device=device)
+        mask[:-denoise_length, -denoise_length:] = 1.
+        return mask
+
+    def forward(self, q, v, q_pos, v_pos, self_attn_idx=None, cross_attn_idx=None, denoise_length=None,
+                denoise_mask=None):
+        """`denoise_mask`: the mask above, if the caller already built it (it is the same for every block)."""
         if denoise_length is None:
             mask = mask_split = None
         else:
             n = q.size(1)
-            mask = torch.zeros(n, n, device=q.device)
-            mask[:-denoise_length, -denoise_length:] = 1.
+            mask = denoise_mask if denoise_mask is not None else self.denoise_mask(n, denoise_length, q.device)
             mask_split = (n - denoise_length, n - denoise_length)
 
         if self.self_attn_block_length == 2 and self.self_attn_combine_style == 'onebyone':
@@ -283,9 +290,10 @@ class TransformerDecoder(nn.Module):
     def forward(self, q, v, q_pos, v_pos, denoise_length=None):
         self_attn_idx = knn_idx(self.k, q_pos, q_pos) if denoise_length is None else None
         cross_attn_idx = knn_idx(self.k, v_pos, q_pos)
+        mask = None if denoise_length is None else CrossAttnBlockApi.denoise_mask(q.size(1), denoise_length, q.device)
         for block in self.blocks:
             q = block(q, v, q_pos, v_pos, self_attn_idx=self_attn_idx, cross_attn_idx=cross_attn_idx,
-                      denoise_length=denoise_length)
+                      denoise_length=denoise_length, denoise_mask=mask)
         return q
 
 

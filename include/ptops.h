@@ -171,6 +171,13 @@ int ptops_attention_forward(const float* q, const float* k, const float* v, int 
                             int split_q, int limit_k, float scale, float* out, float* lse,
                             void* stream);
 
+/* -------------------------------------------------------------- column sums --
+ * out[n] = sum_m x[m,n] for row-major fp32 x [M,N] (N % 4 == 0): the bias gradient of the dense
+ * layers (the `grad.sum(0)` autograd performs for torch.nn.Linear).  Deterministic; workspace of
+ * ptops_colsum_workspace_bytes(M, N) bytes, 16-byte aligned. */
+size_t ptops_colsum_workspace_bytes(int M, int N);
+int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

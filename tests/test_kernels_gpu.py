@@ -310,3 +310,30 @@ def test_attention_rejects_unsupported_shapes(native):
         native.attention_forward(q, q, q, 0, 40, 0.125)
     q48 = torch.randn(1, 2, 64, 48, device="cuda")
     assert not native.attention_supported(q48, q48, 0, 64)
+
+
+def test_packed_self_attention_and_linear_bias_grad(native):
+    """Attention module on the packed-qkv path + Linear with the streaming bias-gradient kernel vs plain torch."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(5)
+    attn = TU.Attention(384, num_heads=6, qkv_bias=True).cuda()
+    x = torch.randn(8, 576, 384, device="cuda", requires_grad=True)
+    mask = torch.zeros(576, 576, device="cuda")
+    mask[:512, 512:] = 1.
+    outs = {}
+    for fast in (True, False):
+        TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = fast
+        for p in attn.parameters():
+            p.grad = None
+        y = attn(x, mask=mask, mask_split=(512, 512))
+        g = torch.autograd.grad(y.square().sum(), [x] + list(attn.parameters()))
+        outs[fast] = [y.detach()] + [t.detach() for t in g]
+    TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = True
+    for a, b in zip(outs[True], outs[False]):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() < 2e-5 * scale
+    # the column-sum kernel itself, against float64
+    g2 = torch.randn(18432, 384, device="cuda")
+    assert (native.colsum(g2).double() - g2.double().sum(0)).abs().max().item() < 2e-3
+    g3 = torch.randn(2050, 96, device="cuda")
+    assert (native.colsum(g3).double() - g3.double().sum(0)).abs().max().item() < 5e-4
