@@ -50,6 +50,9 @@ def _declare(lib):
         "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_emd_forward": (c_int, [P, P, c_int, c_int, c_int] + [P] * 12 + [ctypes.c_float, c_int, P]),
         "ptops_emd_backward": (c_int, [P] * 5 + [c_int] * 3 + [P]),
+        "ptops_edge_select_blocks": (c_int, [c_int]),
+        "ptops_edge_select": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P, P, P, P]),
+        "ptops_edge_scatter": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P]),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
@@ -69,6 +72,7 @@ EXPORTS = (
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_colsum_workspace_bytes", "ptops_colsum",
+    "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
 )
 
 
@@ -503,3 +507,42 @@ def colsum(x):
         ws = torch.empty((max(load().ptops_colsum_workspace_bytes(M, N) // 4, 4),), dtype=torch.float32, device=x.device)
         _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), _stream(x))
     return out
+
+
+def edge_select(P, R, idx, take_max):
+    """P [B,C,Nk], R [B,C,Nq], idx int32 [B,Nq,k], take_max uint8 [C] ->
+    (ysel [B,C,Nq], nsel int32 [B,C,Nq], ysum [B,C,Nq], partial [B,C,nblk,2])."""
+    _check(P, "P", torch.float32, 3)
+    _check(R, "R", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    _check(take_max, "take_max", torch.uint8, 1)
+    dev = _same_device(P, R, idx, take_max)
+    B, C, Nk = P.shape
+    Nq, k = idx.shape[1], idx.shape[2]
+    if tuple(R.shape) != (B, C, Nq) or idx.shape[0] != B or take_max.numel() != C:
+        raise ValueError("edge_select: inconsistent shapes")
+    nblk = load().ptops_edge_select_blocks(Nq)
+    with torch.cuda.device(dev):
+        ysel = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
+        nsel = torch.empty((B, C, Nq), dtype=torch.int32, device=dev)
+        ysum = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
+        partial = torch.empty((B, C, nblk, 2), dtype=torch.float32, device=dev)
+        _call("ptops_edge_select", _ptr(P), _ptr(R), _ptr(idx), _ptr(take_max), B, C, Nk, Nq, k, _ptr(ysel),
+              _ptr(nsel), _ptr(ysum), _ptr(partial), _stream(P))
+    return ysel, nsel, ysum, partial
+
+
+def edge_scatter(dense, sel, idx, nsel, Nk):
+    """dense/sel [B,C,Nq], idx int32 [B,Nq,k], nsel int32 [B,C,Nq] -> T [B,C,Nk]."""
+    _check(dense, "dense", torch.float32, 3)
+    _check(sel, "sel", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    _check(nsel, "nsel", torch.int32, 3)
+    dev = _same_device(dense, sel, idx, nsel)
+    B, C, Nq = dense.shape
+    k = idx.shape[2]
+    with torch.cuda.device(dev):
+        T = torch.empty((B, C, int(Nk)), dtype=torch.float32, device=dev)
+        _call("ptops_edge_scatter", _ptr(dense), _ptr(sel), _ptr(idx), _ptr(nsel), B, C, int(Nk), Nq, k, _ptr(T),
+              _stream(dense))
+    return T

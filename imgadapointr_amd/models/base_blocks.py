@@ -375,6 +375,69 @@ class _EdgeGroup(torch.autograd.Function):
         return gk, gq, None
 
 
+# True: every edge-conv stage runs as the fused gather / statistics / select kernels of csrc/edgeconv.hip
+# (exact algebra, no [B,C,Nq,k] tensors).  False: the reference's literal chain (gather+concat kernel, then
+# Conv2d / GroupNorm / LeakyReLU / max on PyTorch-ROCm) — kept for parity tests.
+FUSED_EDGE_CONV = True
+
+
+class _FusedEdgeConv(torch.autograd.Function):
+    """out[b,c,q] = max_j LeakyReLU(GroupNorm(P[b,c,idx[b,q,j]] + R[b,c,q]))  over the k neighbours j.
+
+    P = W1.x_k and R = (W2-W1).x_q are the two halves of the stage's 1x1 convolution (computed by the
+    caller with ordinary GEMMs, so autograd turns dP / dR into weight and feature gradients).  The
+    GroupNorm statistics run over all (channel-in-group, q, j) edge values, exactly as in the reference
+    where the norm precedes the max (base_blocks.py:527-545); because the affine + LeakyReLU are monotone
+    per channel, the max over j is the max (gamma >= 0) or min (gamma < 0) of the raw edge values."""
+
+    @staticmethod
+    def forward(ctx, P, R, idx, gamma, beta, groups, eps, slope):
+        B, C, Nk = P.shape
+        Nq, k = idx.shape[1], idx.shape[2]
+        take_max = (gamma >= 0).to(torch.uint8)
+        ysel, nsel, ysum, partial = _native.edge_select(P.contiguous(), R.contiguous(), idx, take_max)
+        M = (C // groups) * Nq * k
+        sums = partial.double().view(B, groups, -1, 2).sum(dim=2)             # [B,G,2], fixed order
+        mean = sums[..., 0] / M
+        var = (sums[..., 1] / M - mean * mean).clamp_min(0.0)
+        rstd = (var + eps).rsqrt()
+        cpg = C // groups
+        mean_c = mean.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)     # [B,C,1]
+        rstd_c = rstd.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)
+        yhat = (ysel - mean_c) * rstd_c
+        z = yhat * gamma.view(1, C, 1) + beta.view(1, C, 1)
+        out = torch.nn.functional.leaky_relu(z, slope)
+        ctx.save_for_backward(P, R, idx, gamma, nsel, ysum, yhat, z, mean_c, rstd_c)
+        ctx.cfg = (groups, slope, M, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        P, R, idx, gamma, nsel, ysum, yhat, z, mean_c, rstd_c = ctx.saved_tensors
+        groups, slope, M, k = ctx.cfg
+        B, C, Nk = P.shape
+        cpg = C // groups
+        dz = go * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        dgamma = (dz * yhat).sum(dim=(0, 2))
+        dbeta = dz.sum(dim=(0, 2))
+        gdz = dz * gamma.view(1, C, 1)                                         # d/d(yhat) on the selected edges
+
+        def group_mean(t):                                                     # [B,C,Nq] -> [B,C,1], mean over the group
+            m = t.double().view(B, groups, -1).sum(dim=2) / M
+            return m.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)
+
+        m1, m2 = group_mean(gdz), group_mean(gdz * yhat)
+        S = rstd_c * gdz                                                       # selected-edge term
+        Bg = -(rstd_c * rstd_c) * m2                                           # dy_e = [sel] S + Ag + Bg * y_e
+        Ag = -rstd_c * m1 - Bg * mean_c
+        dR = S + k * Ag + Bg * ysum
+        T = _native.edge_scatter((Bg * R).contiguous(), S.contiguous(), idx, nsel, Nk)
+        cnt = torch.zeros(B, Nk, device=P.device).scatter_add_(
+            1, idx.reshape(B, -1).long(), torch.ones(B, idx.shape[1] * k, device=P.device))
+        dP = T + cnt.unsqueeze(1) * (Ag + Bg * P)
+        return dP, dR, None, dgamma, dbeta, None, None, None
+
+
 class DGCNN_Grouper(nn.Module):
     """Four edge-conv stages with two FPS down-samplings (base_blocks.py:516-629)."""
 
@@ -411,22 +474,39 @@ class DGCNN_Grouper(nn.Module):
             idx = knn_idx(self.k, coor_k.transpose(-1, -2).contiguous(), coor_q.transpose(-1, -2).contiguous())
         return _EdgeGroup.apply(x_k.contiguous(), x_q.contiguous(), idx)
 
+    def edge_conv(self, layer, coor_q, x_q, coor_k, x_k):
+        """One stage: max over the k neighbours of layer(get_graph_feature(...)) -> [B,C',Nq]."""
+        conv, norm, act = layer[0], layer[1], layer[2]
+        fused = (FUSED_EDGE_CONV and x_k.is_cuda and _native.backend_for_testing() is None and self.k <= 32
+                 and x_k.size(2) * 4 <= 64 * 1024 and conv.bias is None)
+        if not fused:
+            return layer(self.get_graph_feature(coor_q, x_q, coor_k, x_k)).max(dim=-1, keepdim=False)[0]
+        with torch.no_grad():
+            idx = knn_idx(self.k, coor_k.transpose(-1, -2).contiguous(), coor_q.transpose(-1, -2).contiguous())
+        C = x_k.size(1)
+        w = conv.weight.view(conv.out_channels, 2 * C)
+        w1, w2 = w[:, :C], w[:, C:]
+        P = torch.matmul(w1, x_k)                      # [B,C',Nk]   W1 . x_k
+        R = torch.matmul(w2 - w1, x_q)                 # [B,C',Nq]   (W2 - W1) . x_q
+        return _FusedEdgeConv.apply(P, R, idx, norm.weight, norm.bias, norm.num_groups, norm.eps,
+                                    act.negative_slope)
+
     def forward(self, x, num, fps_idx=None):
         """x [B,N,3], num e.g. [512, 256] -> coor [B,num[1],3], f [B,num[1],128]."""
         x = x.transpose(-1, -2).contiguous()
         coor = x
         f = self.input_trans(x)
 
-        f = self.layer1(self.get_graph_feature(coor, f, coor, f)).max(dim=-1, keepdim=False)[0]
+        f = self.edge_conv(self.layer1, coor, f, coor, f)
 
         coor_q, f_q = self.fps_downsample(coor, f, num[0], fps_idx=fps_idx)
-        f = self.layer2(self.get_graph_feature(coor_q, f_q, coor, f)).max(dim=-1, keepdim=False)[0]
+        f = self.edge_conv(self.layer2, coor_q, f_q, coor, f)
         coor = coor_q.contiguous()
 
-        f = self.layer3(self.get_graph_feature(coor, f, coor, f)).max(dim=-1, keepdim=False)[0]
+        f = self.edge_conv(self.layer3, coor, f, coor, f)
 
         coor_q, f_q = self.fps_downsample(coor, f, num[1])
-        f = self.layer4(self.get_graph_feature(coor_q, f_q, coor, f)).max(dim=-1, keepdim=False)[0]
+        f = self.edge_conv(self.layer4, coor_q, f_q, coor, f)
         coor = coor_q
 
         return coor.transpose(-1, -2).contiguous(), f.transpose(-1, -2).contiguous()

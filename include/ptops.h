@@ -171,6 +171,22 @@ int ptops_attention_forward(const float* q, const float* k, const float* v, int 
                             int split_q, int limit_k, float scale, float* out, float* lse,
                             void* stream);
 
+/* ------------------------------------------------- fused edge-conv stage ----
+ * One stage of DGCNN_Grouper (models/base_blocks.py:565-623): with P = W1.x_k [B,C,Nk] and
+ * R = (W2-W1).x_q [B,C,Nq] (the 1x1 convolution split over its two input halves) the value on edge
+ * (q,j) is y = P[idx[q,j]] + R[q].  ptops_edge_select returns per (b,c,q) the max (take_max[c] != 0)
+ * or min of y over the k neighbours (ysel), the source index that produced it (nsel), sum_j y (ysum) and
+ * per-workgroup partial sums {sum y, sum y^2} (partial [B,C,ptops_edge_select_blocks(Nq),2]) for the
+ * GroupNorm statistics.  ptops_edge_scatter is the edge part of the backward:
+ * T[b,c,n] = sum_{(q,j): idx[q,j]=n} dense[b,c,q] + sum_{q: nsel[b,c,q]=n} sel[b,c,q].   k <= 32. */
+int ptops_edge_select_blocks(int Nq);
+int ptops_edge_select(const float* P, const float* R, const int32_t* idx,
+                      const unsigned char* take_max, int B, int C, int Nk, int Nq, int k,
+                      float* ysel, int32_t* nsel, float* ysum, float* partial, void* stream);
+int ptops_edge_scatter(const float* dense, const float* sel, const int32_t* idx,
+                       const int32_t* nsel, int B, int C, int Nk, int Nq, int k, float* T,
+                       void* stream);
+
 /* -------------------------------------------------------------- column sums --
  * out[n] = sum_m x[m,n] for row-major fp32 x [M,N] (N % 4 == 0): the bias gradient of the dense
  * layers (the `grad.sum(0)` autograd performs for torch.nn.Linear).  Deterministic; workspace of
