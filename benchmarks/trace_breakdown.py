@@ -1,0 +1,92 @@
+"""Steady-state per-step kernel breakdown from a rocprofv3 kernel trace of bench.py.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o step -- python3 bench.py --steps 10 --warmup 5
+    python3 benchmarks/trace_breakdown.py /tmp/prof/step_kernel_trace.csv --steps 8 > profiles/roundN/step_breakdown.txt
+
+The warm-up steps contain TunableOp / MIOpen search kernels, so the whole-run --stats summary is
+not a picture of a train step.  This tool keeps only the last `--steps` steps, delimited by the last
+launch of each step (the optimizer's final multi-tensor kernel), and groups kernels by family.
+"""
+import argparse
+import collections
+import csv
+import re
+
+FAMILIES = [
+    ("ptops: chamfer", r"chamfer_"),
+    ("ptops: knn", r"knn_kernel"),
+    ("ptops: fps", r"fps_kernel"),
+    ("ptops: edge-conv", r"edge_select|edge_scatter|edge_group"),
+    ("ptops: gather/index", r"gather_|index_points"),
+    ("ptops: attention fwd", r"attn_fwd_kernel"),
+    ("ptops: colsum", r"colsum_"),
+    ("attention bwd (aten)", r"fmha|attention|AttentionBackward|efficient_attention"),
+    ("GEMM (hipBLASLt/rocBLAS/CK)", r"^Cijk_|gemm|Gemm"),
+    ("conv (MIOpen)", r"conv|Conv|igemm|miopen"),
+    ("norm", r"layer_norm|LayerNorm|group_norm|GroupNorm|RowwiseMoments|batch_norm|BatchNorm"),
+    ("reduce", r"reduce_kernel|Reduce"),
+    ("optimizer", r"multi_tensor_apply"),
+    ("copy / cat / fill", r"CatArray|copy|Copy|fill|Fill|memcpy|memset"),
+    ("sort / scatter / index", r"sort|Sort|scatter|index_|gather"),
+    ("elementwise", r"elementwise|vectorized"),
+]
+
+
+def family(name):
+    for fam, pat in FAMILIES:
+        if re.search(pat, name):
+            return fam
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--marker", default="chamfer_grad_kernel", help="kernel launched a fixed number of times per step")
+    ap.add_argument("--top", type=int, default=25)
+    a = ap.parse_args()
+
+    rows = []
+    with open(a.trace) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+    # markers per step: smallest period such that the kernel count between successive groups is constant
+    per = 1
+    for cand in (1, 2, 3, 4, 6, 8):
+        if len(marks) < cand * (a.steps + 1):
+            break
+        tail = marks[-cand * (a.steps + 1):][::cand]
+        gaps = {tail[i + 1] - tail[i] for i in range(len(tail) - 1)}
+        if len(gaps) == 1:
+            per = cand
+            break
+    tail = marks[-per * (a.steps + 1):][::per]
+    lo, hi = tail[0], tail[-1]
+    win = rows[lo:hi]
+    wall = (rows[hi][0] - rows[lo][0]) / a.steps / 1e6
+    fam_t, fam_n = collections.Counter(), collections.Counter()
+    ker_t, ker_n = collections.Counter(), collections.Counter()
+    for s, e, n in win:
+        f = family(n)
+        fam_t[f] += e - s
+        fam_n[f] += 1
+        short = re.sub(r"<.*", "", n)[:90]
+        ker_t[short] += e - s
+        ker_n[short] += 1
+    busy = sum(fam_t.values()) / a.steps / 1e6
+    print(f"steps analysed: {a.steps} (marker '{a.marker}' x{per}/step, {len(win) // a.steps} launches/step)")
+    print(f"wall per step {wall:.2f} ms, kernel-busy per step {busy:.2f} ms")
+    print(f"{'family':34s} {'ms/step':>9s} {'%busy':>7s} {'launches/step':>14s}")
+    for f, t in fam_t.most_common():
+        print(f"{f:34s} {t / a.steps / 1e6:9.3f} {100 * t / sum(fam_t.values()):7.1f} {fam_n[f] / a.steps:14.1f}")
+    print(f"\ntop {a.top} kernels")
+    for k, t in ker_t.most_common(a.top):
+        print(f"{t / a.steps / 1e6:9.3f} ms  x{ker_n[k] / a.steps:7.1f}  {k}")
+
+
+if __name__ == "__main__":
+    main()

@@ -423,7 +423,7 @@ class _FusedEdgeConv(torch.autograd.Function):
         gdz = dz * gamma.view(1, C, 1)                                         # d/d(yhat) on the selected edges
 
         def group_mean(t):                                                     # [B,C,Nq] -> [B,C,1], mean over the group
-            m = t.double().view(B, groups, -1).sum(dim=2) / M
+            m = t.double().reshape(B, groups, -1).sum(dim=2) / M
             return m.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)
 
         m1, m2 = group_mean(gdz), group_mean(gdz * yhat)
