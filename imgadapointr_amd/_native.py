@@ -56,6 +56,7 @@ def _declare(lib):
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
+        "ptops_attention_backward": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -71,7 +72,7 @@ EXPORTS = (
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
-    "ptops_attention_forward", "ptops_colsum_workspace_bytes", "ptops_colsum",
+    "ptops_attention_forward", "ptops_attention_backward", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
 )
 
@@ -494,6 +495,27 @@ def attention_forward(q, k, v, split_q, limit_k, scale):
         _call("ptops_attention_forward", _ptr(q), _ptr(k), _ptr(v), B, H, Nq, Nk, qs, ks, vs, int(split_q),
               int(limit_k), ctypes.c_float(float(scale)), _ptr(out), _ptr(lse), _stream(q))
     return out, lse
+
+
+def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv):
+    """Gradients of attention_forward written into dq [B,H,Nq,64] / dk, dv [B,H,Nk,64] (strided views, e.g.
+    the slices of one packed allocation).  out/dout [B,Nq,H,64] contiguous, lse [B,H,Nq] from the forward."""
+    qs, ks, vs = _bhnd_strides(q, "q"), _bhnd_strides(k, "k"), _bhnd_strides(v, "v")
+    dqs, dks, dvs = _bhnd_strides(dq, "dq"), _bhnd_strides(dk, "dk"), _bhnd_strides(dv, "dv")
+    dev = _same_device(q, k, v, out, dout, lse, dq, dk, dv)
+    B, H, Nq, _ = q.shape
+    Nk = k.size(2)
+    if tuple(out.shape) != (B, Nq, H, 64) or tuple(dout.shape) != (B, Nq, H, 64) or tuple(lse.shape) != (B, H, Nq):
+        raise ValueError("attention_backward: out/dout must be [B,Nq,H,64] and lse [B,H,Nq]")
+    if tuple(dq.shape) != tuple(q.shape) or tuple(dk.shape) != tuple(k.shape) or tuple(dv.shape) != tuple(v.shape):
+        raise ValueError("attention_backward: gradient views must have the shapes of q / k / v")
+    if not (out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attention_backward: out, dout and lse must be contiguous")
+    with torch.cuda.device(dev):
+        delta = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
+        _call("ptops_attention_backward", _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), B, H, Nq, Nk,
+              qs, ks, vs, dqs, dks, dvs, int(split_q), int(limit_k), ctypes.c_float(float(scale)), _ptr(dq), _ptr(dk),
+              _ptr(dv), _ptr(delta), _stream(q))
 
 
 def colsum(x):

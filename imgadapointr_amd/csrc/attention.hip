@@ -186,6 +186,320 @@ __global__ __launch_bounds__(W * 64, 3) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Backward.  With P = softmax(scale q k^T), D_i = sum_c dO_ic O_ic and dS = P o (dP - D), dP = dO v^T:
+//   dq = scale dS k,   dk = scale dS^T q,   dv = P^T dO.
+// Two kernels, both deterministic (no atomics) and both built from the forward's two MFMA patterns
+// "row-major LDS tile x register-resident operand" and "accumulator reused as the B operand":
+//   dq  : query tile stationary (Q^T, dO^T in registers), K/V tiles stream through LDS.
+//         S^T = K Q^T, dP^T = V dO^T (queries on lanes, so lse / D are per-lane scalars),
+//         dQ^T += K^T dS^T with B = the dS^T accumulator.  Also emits D for the second kernel.
+//   dkv : key tile stationary (K^T, V^T in registers), Q/dO tiles stream through LDS.
+//         S = Q K^T, dP = dO V^T (keys on lanes), dV^T += dO^T P and dK^T += Q^T dS with B = P / dS.
+// S and dP are recomputed in both (7 GEMMs instead of 5): the price of not reducing dq across key tiles.
+struct AttnBwdArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  const float* o;     // [B, Nq, H, 64] contiguous (forward output)
+  const float* dout;  // [B, Nq, H, 64] contiguous
+  const float* lse;   // [B, H, Nq] base-2
+  float* delta;       // [B, H, Nq]  D_i, written by the dq kernel, read by the dkv kernel
+  float* dq;
+  float* dk;
+  float* dv;
+  long long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn;
+  long long dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn;
+  int H, Nq, Nk;
+  int split_q, limit_k;
+  float scale, scale_log2e;
+};
+
+// accumulator (rows = dims, column = lane&31) -> 64 contiguous floats of row `dst`, times `mul`
+__device__ __forceinline__ void store_dim_major(float* dst, const f32x16& a0, const f32x16& a1, int h, float mul) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 w0 = {a0[4 * g] * mul, a0[4 * g + 1] * mul, a0[4 * g + 2] * mul, a0[4 * g + 3] * mul};
+    f32x4 w1 = {a1[4 * g] * mul, a1[4 * g + 1] * mul, a1[4 * g + 2] * mul, a1[4 * g + 3] * mul};
+    *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = w0;
+    *reinterpret_cast<f32x4*>(dst + 32 + 8 * g + 4 * h) = w1;
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64, 2) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sK[2][kTK * kLd];
+  __shared__ __attribute__((aligned(16))) float sV[2][kTK * kLd];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int q0 = (blockIdx.x * W + wave) * 32;
+  const bool active = q0 < a.Nq;
+  const float* kb = a.k + b * a.k_sb + head * a.k_sh;
+  const float* vb = a.v + b * a.v_sb + head * a.v_sh;
+
+  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
+  const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
+  const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
+
+  float qf[32], dof[32];
+  float lse = 0.0f, dlt = 0.0f;
+  if (active) {
+    const float* qp = a.q + b * a.q_sb + head * a.q_sh + (long long)(q0 + j) * a.q_sn + 32 * h;
+    const long long orow = (((long long)b * a.Nq + q0 + j) * a.H + head) * kD + 32 * h;
+    const float* dop = a.dout + orow;
+    const float* op = a.o + orow;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * t);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(dop + 4 * t);
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(op + 4 * t);
+      qf[4 * t + 0] = q4.x * a.scale_log2e;
+      qf[4 * t + 1] = q4.y * a.scale_log2e;
+      qf[4 * t + 2] = q4.z * a.scale_log2e;
+      qf[4 * t + 3] = q4.w * a.scale_log2e;
+      dof[4 * t + 0] = d4.x;
+      dof[4 * t + 1] = d4.y;
+      dof[4 * t + 2] = d4.z;
+      dof[4 * t + 3] = d4.w;
+      dlt = fmaf(d4.x, o4.x, dlt);
+      dlt = fmaf(d4.y, o4.y, dlt);
+      dlt = fmaf(d4.z, o4.z, dlt);
+      dlt = fmaf(d4.w, o4.w, dlt);
+    }
+    dlt += other_half(dlt);
+    const long long li = ((long long)b * a.H + head) * a.Nq + q0 + j;
+    lse = a.lse[li];
+    if (h == 0) a.delta[li] = dlt;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      qf[t] = 0.0f;
+      dof[t] = 0.0f;
+    }
+  }
+
+  f32x16 g0 = {0}, g1 = {0};  // dQ^T accumulators: dims 0..31 / 32..63, query on the lane
+
+  constexpr int kPerThread = (kTK * (kD / 4) + W * 64 - 1) / (W * 64);
+  f32x4 kreg[kPerThread], vreg[kPerThread];
+  auto fetch_tile = [&](int key0) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        kreg[u] = *reinterpret_cast<const f32x4*>(kb + (long long)(key0 + r) * a.k_sn + c4);
+        vreg[u] = *reinterpret_cast<const f32x4*>(vb + (long long)(key0 + r) * a.v_sn + c4);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<f32x4*>(&sK[buf][r * kLd + c4]) = kreg[u];
+        *reinterpret_cast<f32x4*>(&sV[buf][r * kLd + c4]) = vreg[u];
+      }
+    }
+  };
+
+  const int ntiles = blk_keys / kTK;
+  if (ntiles > 0) {
+    fetch_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);
+    if (t * kTK < my_keys) {
+      f32x16 s = {0}, dp = {0};
+      const float* kr = &sK[buf][j * kLd + 32 * h];
+      const float* vr = &sV[buf][j * kLd + 32 * h];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + 4 * g);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + 4 * g);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[4 * g + 0], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.x, dof[4 * g + 0], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[4 * g + 1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.y, dof[4 * g + 1], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[4 * g + 2], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.z, dof[4 * g + 2], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[4 * g + 3], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.w, dof[4 * g + 3], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - lse) * (dp[r] - dlt);  // dS^T (unscaled)
+      const float* kc = &sK[buf][(4 * h) * kLd + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2);
+        const float k0v = kc[key * kLd], k1v = kc[key * kLd + 32];
+        g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0v, s[r], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1v, s[r], g1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active)
+    store_dim_major(a.dq + b * a.dq_sb + head * a.dq_sh + (long long)(q0 + j) * a.dq_sn, g0, g1, h, a.scale);
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float sQ[2][kTK * kLd];
+  __shared__ __attribute__((aligned(16))) float sO[2][kTK * kLd];   // dO tile
+  __shared__ __attribute__((aligned(16))) float sL[2][2 * kTK];     // lse[32], delta[32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int k0 = (blockIdx.x * W + wave) * 32;
+  const bool active = k0 < a.Nk;
+  const float* qb = a.q + b * a.q_sb + head * a.q_sh;
+  const float* dob = a.dout + ((long long)b * a.Nq * a.H + head) * kD;  // row stride H*64
+  const float* lb = a.lse + ((long long)b * a.H + head) * a.Nq;
+  const float* db = a.delta + ((long long)b * a.H + head) * a.Nq;
+  const long long do_sn = (long long)a.H * kD;
+
+  // query tiles this workgroup walks: keys >= limit_k are seen only by queries >= split_q
+  const int blk_k0 = blockIdx.x * W * 32;
+  const int blk_qstart = (blk_k0 >= a.limit_k) ? a.split_q : 0;
+  const int my_qstart = active ? ((k0 >= a.limit_k) ? a.split_q : 0) : a.Nq;
+
+  float kf[32], vf[32];
+  if (active) {
+    const float* kp = a.k + b * a.k_sb + head * a.k_sh + (long long)(k0 + j) * a.k_sn + 32 * h;
+    const float* vp = a.v + b * a.v_sb + head * a.v_sh + (long long)(k0 + j) * a.v_sn + 32 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 4 * t);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp + 4 * t);
+      kf[4 * t + 0] = k4.x * a.scale_log2e;
+      kf[4 * t + 1] = k4.y * a.scale_log2e;
+      kf[4 * t + 2] = k4.z * a.scale_log2e;
+      kf[4 * t + 3] = k4.w * a.scale_log2e;
+      vf[4 * t + 0] = v4.x;
+      vf[4 * t + 1] = v4.y;
+      vf[4 * t + 2] = v4.z;
+      vf[4 * t + 3] = v4.w;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      kf[t] = 0.0f;
+      vf[t] = 0.0f;
+    }
+  }
+
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};  // dK^T / dV^T: rows = dims, key on the lane
+
+  constexpr int kPerThread = (kTK * (kD / 4) + W * 64 - 1) / (W * 64);
+  f32x4 qreg[kPerThread], oreg[kPerThread];
+  float lreg = 0.0f;
+  auto fetch_tile = [&](int q0) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        qreg[u] = *reinterpret_cast<const f32x4*>(qb + (long long)(q0 + r) * a.q_sn + c4);
+        oreg[u] = *reinterpret_cast<const f32x4*>(dob + (long long)(q0 + r) * do_sn + c4);
+      }
+    }
+    if (tid < 64) lreg = (tid < 32) ? lb[q0 + tid] : db[q0 + tid - 32];
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = tid + u * W * 64;
+      if (e < kTK * (kD / 4)) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<f32x4*>(&sQ[buf][r * kLd + c4]) = qreg[u];
+        *reinterpret_cast<f32x4*>(&sO[buf][r * kLd + c4]) = oreg[u];
+      }
+    }
+    if (tid < 64) sL[buf][tid] = lreg;
+  };
+
+  const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
+  if (t_begin < t_end) {
+    fetch_tile(t_begin * kTK);
+    store_tile(t_begin & 1);
+  }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < t_end) fetch_tile((t + 1) * kTK);
+    if (t * kTK >= my_qstart) {
+      // ---- S = Q K^T, dP = dO V^T  (rows = queries (r&3)+8(r>>2)+4h, column = key j) --------------
+      f32x16 s = {0}, dp = {0};
+      const float* qr = &sQ[buf][j * kLd + 32 * h];
+      const float* orow = &sO[buf][j * kLd + 32 * h];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qr + 4 * g);
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 4 * g);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[4 * g + 0], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.x, vf[4 * g + 0], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[4 * g + 1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.y, vf[4 * g + 1], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[4 * g + 2], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.z, vf[4 * g + 2], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[4 * g + 3], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.w, vf[4 * g + 3], dp, 0, 0, 0);
+      }
+      // ---- P and dS; lse / D of the 16 query rows this half holds: 4 broadcast b128 reads each --------
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[buf][8 * g + 4 * h]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sL[buf][kTK + 8 * g + 4 * h]);
+        const float p0 = __builtin_amdgcn_exp2f(s[4 * g + 0] - l4.x);
+        const float p1 = __builtin_amdgcn_exp2f(s[4 * g + 1] - l4.y);
+        const float p2 = __builtin_amdgcn_exp2f(s[4 * g + 2] - l4.z);
+        const float p3 = __builtin_amdgcn_exp2f(s[4 * g + 3] - l4.w);
+        s[4 * g + 0] = p0;
+        s[4 * g + 1] = p1;
+        s[4 * g + 2] = p2;
+        s[4 * g + 3] = p3;
+        dp[4 * g + 0] = p0 * (dp[4 * g + 0] - d4.x);
+        dp[4 * g + 1] = p1 * (dp[4 * g + 1] - d4.y);
+        dp[4 * g + 2] = p2 * (dp[4 * g + 2] - d4.z);
+        dp[4 * g + 3] = p3 * (dp[4 * g + 3] - d4.w);
+      }
+      // ---- dV^T += dO^T P, dK^T += Q^T dS : k-step r uses query rows (r&3)+8(r>>2) [+4 in half 1] ----
+      const float* oc = &sO[buf][(4 * h) * kLd + j];
+      const float* qc = &sQ[buf][(4 * h) * kLd + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const float o0v = oc[row * kLd], o1v = oc[row * kLd + 32];
+        const float q0v = qc[row * kLd], q1v = qc[row * kLd + 32];
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o0v, s[r], dv0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0v, dp[r], dk0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o1v, s[r], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1v, dp[r], dk1, 0, 0, 0);
+      }
+    }
+    if (t + 1 < t_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active) {
+    store_dim_major(a.dk + b * a.dk_sb + head * a.dk_sh + (long long)(k0 + j) * a.dk_sn, dk0, dk1, h, a.scale);
+    store_dim_major(a.dv + b * a.dv_sb + head * a.dv_sh + (long long)(k0 + j) * a.dv_sn, dv0, dv1, h, 1.0f);
+  }
+}
+
 }  // namespace
 
 PTOPS_API int ptops_attention_forward(const float* q, const float* k, const float* v, int B, int H, int Nq,
@@ -223,4 +537,63 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
     default: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(64), 0, stream, a); break;
   }
   return ptops::check_launch("attn_fwd_kernel");
+}
+
+PTOPS_API int ptops_attention_backward(const float* q, const float* k, const float* v, const float* out,
+                                       const float* dout, const float* lse, int B, int H, int Nq, int Nk,
+                                       const long long* q_strides, const long long* k_strides,
+                                       const long long* v_strides, const long long* dq_strides,
+                                       const long long* dk_strides, const long long* dv_strides, int split_q,
+                                       int limit_k, float scale, float* dq, float* dk, float* dv, float* delta,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && H >= 1 && Nq >= 0 && Nk >= 1, "attention_backward: bad size");
+  if (B == 0 || Nq == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && delta && q_strides && k_strides && v_strides &&
+                    dq_strides && dk_strides && dv_strides,
+                "attention_backward: null pointer");
+  PTOPS_REQUIRE(Nq % 32 == 0 && Nk % 32 == 0, "attention_backward: token counts must be multiples of 32 (Nq=%d Nk=%d)", Nq, Nk);
+  PTOPS_REQUIRE(split_q >= 0 && split_q <= Nq && split_q % 32 == 0 && limit_k >= 32 && limit_k <= Nk && limit_k % 32 == 0,
+                "attention_backward: mask split (%d, %d) must be multiples of 32 within range", split_q, limit_k);
+  for (int i = 0; i < 3; ++i)
+    PTOPS_REQUIRE(q_strides[i] % 4 == 0 && k_strides[i] % 4 == 0 && v_strides[i] % 4 == 0 && dq_strides[i] % 4 == 0 &&
+                      dk_strides[i] % 4 == 0 && dv_strides[i] % 4 == 0,
+                  "attention_backward: strides must keep rows 16-byte aligned");
+  PTOPS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq |
+                  (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+                "attention_backward: pointers must be 16-byte aligned");
+  AttnBwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = out; a.dout = dout; a.lse = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
+  a.dq_sb = dq_strides[0]; a.dq_sh = dq_strides[1]; a.dq_sn = dq_strides[2];
+  a.dk_sb = dk_strides[0]; a.dk_sh = dk_strides[1]; a.dk_sn = dk_strides[2];
+  a.dv_sb = dv_strides[0]; a.dv_sh = dv_strides[1]; a.dv_sn = dv_strides[2];
+  a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
+  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  {  // dq (+ delta): one wave per 32-query tile; two waves per SIMD fit, so 4-wave workgroups (two per CU)
+     // fill a CU where 3-wave ones would leave a quarter of it empty; the last workgroup may be partly idle
+    const int tiles = Nq / 32;
+    const int W = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
+    dim3 grid(ptops::ceil_div(tiles, W), B * H);
+    switch (W) {
+      case 4: hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(128), 0, stream, a); break;
+      default: hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(64), 0, stream, a); break;
+    }
+    int rc = ptops::check_launch("attn_bwd_dq_kernel");
+    if (rc != PTOPS_OK) return rc;
+  }
+  {  // dk, dv: one wave per 32-key tile, 4 per workgroup (the last workgroup may be partly idle)
+    const int tiles = Nk / 32;
+    const int W = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
+    dim3 grid(ptops::ceil_div(tiles, W), B * H);
+    switch (W) {
+      case 4: hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(256), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid, dim3(128), 0, stream, a); break;
+      default: hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(64), 0, stream, a); break;
+    }
+  }
+  return ptops::check_launch("attn_bwd_dkv_kernel");
 }

@@ -28,6 +28,8 @@ USE_SDPA = True
 # PyTorch-ROCm's memory-efficient attention backward (aten::_efficient_attention_backward), which
 # consumes the same (out, logsumexp) pair.  Falls back to SDPA for shapes the kernel does not cover.
 USE_MFMA_ATTENTION = True
+# True: the attention backward runs on the library's two MFMA kernels; False: aten::_efficient_attention_backward
+USE_MFMA_ATTENTION_BWD = True
 _LN2 = 0.6931471805599453
 _bias_cache = {}
 _zero_cache = {}
@@ -202,6 +204,13 @@ class _MFMAAttention(torch.autograd.Function):
         split_q, limit_k = ctx.mask
         B, H, Nq, _ = q.shape
         Nk = k.size(2)
+        if USE_MFMA_ATTENTION_BWD:
+            # gradients in the token-major layout the projections produce ([B,N,h,d] viewed as [B,h,N,d])
+            gq = torch.empty((B, Nq, H, 64), dtype=q.dtype, device=q.device).transpose(1, 2)
+            gkv = torch.empty((B, Nk, 2, H, 64), dtype=q.dtype, device=q.device)
+            gk, gv = gkv.permute(2, 0, 3, 1, 4).unbind(0)
+            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv)
+            return gq, gk, gv, None, None, None
         bias = None
         if split_q > 0 and limit_k < Nk:
             bias = _block_bias(Nq, Nk, split_q, limit_k, q.device).expand(B, H, Nq, Nk)
@@ -230,6 +239,12 @@ class _MFMASelfAttention(torch.autograd.Function):
         qkv, out, lse2 = ctx.saved_tensors
         split_q, limit_k = ctx.mask
         B, N, _, H, D = qkv.shape
+        if USE_MFMA_ATTENTION_BWD:
+            g = torch.empty_like(qkv)
+            q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+            gq, gk, gv = g.permute(2, 0, 3, 1, 4).unbind(0)
+            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv)
+            return g, None, None, None
         q, k, v = qkv.unbind(2)                               # [B,N,h,d] views, the layout the op expects
         bias = None
         if split_q > 0 and limit_k < N:

@@ -171,6 +171,19 @@ int ptops_attention_forward(const float* q, const float* k, const float* v, int 
                             int split_q, int limit_k, float scale, float* out, float* lse,
                             void* stream);
 
+/* Backward of ptops_attention_forward (replaces the autograd chain through softmax / matmul of
+ * models/Transformer_utils.py:89-159).  out, dout [B,Nq,H,64] contiguous; lse as returned by the
+ * forward; dq/dk/dv are written through their own (batch, head, token) strides (rows of 64 contiguous
+ * floats, e.g. the three slices of a packed [B,N,3,H,64] gradient); delta [B,H,Nq] is scratch
+ * (sum_c dout*out per query).  Deterministic: no atomics. */
+int ptops_attention_backward(const float* q, const float* k, const float* v, const float* out,
+                             const float* dout, const float* lse, int B, int H, int Nq, int Nk,
+                             const long long* q_strides, const long long* k_strides,
+                             const long long* v_strides, const long long* dq_strides,
+                             const long long* dk_strides, const long long* dv_strides,
+                             int split_q, int limit_k, float scale, float* dq, float* dk,
+                             float* dv, float* delta, void* stream);
+
 /* ------------------------------------------------- fused edge-conv stage ----
  * One stage of DGCNN_Grouper (models/base_blocks.py:565-623): with P = W1.x_k [B,C,Nk] and
  * R = (W2-W1).x_q [B,C,Nq] (the 1x1 convolution split over its two input halves) the value on edge

@@ -271,7 +271,8 @@ def test_metrics_with_emd(native, ref):
 
 
 @pytest.mark.parametrize("Nq,Nk,split,limit", [(576, 576, 512, 512), (576, 256, 0, 256), (256, 256, 0, 256),
-                                                (512, 512, 0, 512), (96, 64, 32, 32), (32, 32, 0, 32)])
+                                                (512, 512, 0, 512), (96, 64, 32, 32), (32, 32, 0, 32),
+                                                (160, 224, 64, 96), (64, 608, 32, 576)])
 def test_attention_forward_and_backward(native, Nq, Nk, split, limit):
     """fp32 MFMA attention vs an explicit float64 softmax(q k^T scale + mask) v, values and gradients."""
     from imgadapointr_amd.models.Transformer_utils import _MFMAAttention
@@ -321,17 +322,19 @@ def test_packed_self_attention_and_linear_bias_grad(native):
     mask = torch.zeros(576, 576, device="cuda")
     mask[:512, 512:] = 1.
     outs = {}
-    for fast in (True, False):
+    for fast, native_bwd in ((True, True), (True, False), (False, False)):
         TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = fast
+        TU.USE_MFMA_ATTENTION_BWD = native_bwd
         for p in attn.parameters():
             p.grad = None
         y = attn(x, mask=mask, mask_split=(512, 512))
         g = torch.autograd.grad(y.square().sum(), [x] + list(attn.parameters()))
-        outs[fast] = [y.detach()] + [t.detach() for t in g]
-    TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = True
-    for a, b in zip(outs[True], outs[False]):
-        scale = max(1.0, b.abs().max().item())
-        assert (a - b).abs().max().item() < 2e-5 * scale
+        outs[(fast, native_bwd)] = [y.detach()] + [t.detach() for t in g]
+    TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = TU.USE_MFMA_ATTENTION_BWD = True
+    for key in ((True, True), (True, False)):
+        for a, b in zip(outs[key], outs[(False, False)]):
+            scale = max(1.0, b.abs().max().item())
+            assert (a - b).abs().max().item() < 2e-5 * scale, key
     # the column-sum kernel itself, against float64
     g2 = torch.randn(18432, 384, device="cuda")
     assert (native.colsum(g2).double() - g2.double().sum(0)).abs().max().item() < 2e-3
