@@ -1,0 +1,44 @@
+"""aten-level view of one train step (which ops own the element-wise / copy / reduce kernels).
+
+    python benchmarks/op_profile.py > gpurun_out/op_profile.txt
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from imgadapointr_amd import _native  # noqa: E402
+from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
+from imgadapointr_amd.tools import builder  # noqa: E402
+from imgadapointr_amd.tools.runner import TrainStep  # noqa: E402
+from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
+
+
+def main():
+    device = torch.device("cuda", 0)
+    _native.load()
+    enable_tuned_gemm()
+    cfg = bench.load_cfg()
+    torch.manual_seed(0)
+    model = build_model_from_cfg(cfg.model).to(device)
+    model.train()
+    step = TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
+    partial = (torch.rand(bench.BATCH, bench.N_PARTIAL, 3) - 0.5).to(device)
+    gt = (torch.rand(bench.BATCH, bench.N_GT, 3) - 0.5).to(device)
+    for _ in range(5):
+        step(partial, gt)
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(3):
+            step(partial, gt)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=50, max_name_column_width=70))
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=90,
+                                                             max_name_column_width=50, max_shapes_column_width=90))
+
+
+if __name__ == "__main__":
+    main()

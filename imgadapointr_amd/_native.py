@@ -518,6 +518,9 @@ def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk,
               _ptr(dv), _ptr(delta), _stream(q))
 
 
+_colsum_ws = {}
+
+
 def colsum(x):
     """x [M,N] float32 contiguous (N % 4 == 0) -> column sums [N] (deterministic)."""
     if _test_backend is not None:
@@ -525,9 +528,15 @@ def colsum(x):
     _check(x, "x", torch.float32, 2)
     M, N = x.shape
     with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device)
+        need = max(load().ptops_colsum_workspace_bytes(M, N), 16)
+        key = (x.device.index, stream.cuda_stream)
+        ws = _colsum_ws.get(key)
+        if ws is None or ws.numel() < need:          # one scratch buffer per (device, stream), grown on demand
+            ws = torch.empty((max(need, 1 << 22),), dtype=torch.uint8, device=x.device)
+            _colsum_ws[key] = ws
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
-        ws = torch.empty((max(load().ptops_colsum_workspace_bytes(M, N) // 4, 4),), dtype=torch.float32, device=x.device)
-        _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), _stream(x))
+        _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
     return out
 
 

@@ -1,49 +1,76 @@
 // Column sums of a row-major fp32 matrix: out[n] = sum_m x[m, n]  (bias gradients of the dense layers).
 //
-// PyTorch's generic reduce kernel runs this shape (M = 8192..18432 rows, N = 96..1152 columns) on 2-5
+// PyTorch's generic reduce kernel runs this shape (M = 8192..18432 rows, N = 96..1536 columns) on 2-5
 // workgroups at ~1.4 TB/s; it is a pure streaming read, so it is laid out for the memory system instead:
-// 16 lanes x float4 cover 64 contiguous columns (256 B per row), 16 row-lanes per workgroup walk the
-// rows, the grid has (N/64) x S workgroups with S row slabs, each writing one partial row; a second
-// tiny launch adds the S partials in a fixed order (deterministic, no atomics).
+// 16 lanes x float4 cover 64 contiguous columns (256 B per row), 16 row-lanes per workgroup walk a slab
+// of 128 rows with eight independent loads in flight per lane; the grid has (N/64) x S workgroups, each
+// writing one partial row.  A second small launch adds the S partials in a fixed order (deterministic, no
+// atomics, no device-wide fences: a single-launch variant with a "last workgroup folds" ticket was 5x
+// slower because every workgroup's release fence writes back its XCD's L2).
 #include "ptops_common.h"
 
 namespace {
 
-constexpr int kRowsPerBlock = 512;
+constexpr int kRowsPerBlock = 128;
+
+__device__ __forceinline__ float4 fold16(float4 (*red)[16], float4 acc, int cx, int ry) {
+  red[ry][cx] = acc;
+  __syncthreads();
+  float4 s = red[0][cx];
+#pragma unroll
+  for (int t = 1; t < 16; ++t) {
+    const float4 v = red[t][cx];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  return s;
+}
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int M, int N,
                                                              float* __restrict__ partial) {
   __shared__ float4 red[16][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int col = (blockIdx.x * 16 + cx) * 4;
-  const int r0 = blockIdx.y * kRowsPerBlock, r1 = min(M, r0 + kRowsPerBlock);
+  const bool in = col < N;
+  const int r0 = blockIdx.y * kRowsPerBlock;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < N) {
-    for (int r = r0 + ry; r < r1; r += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * N + col);
+  if (in) {
+    const float* base = x + (size_t)r0 * N + col;
+    if (r0 + kRowsPerBlock <= M) {
+      float4 v[kRowsPerBlock / 16];
+#pragma unroll
+      for (int u = 0; u < kRowsPerBlock / 16; ++u)
+        v[u] = *reinterpret_cast<const float4*>(base + (size_t)(ry + 16 * u) * N);
+#pragma unroll
+      for (int u = 0; u < kRowsPerBlock / 16; ++u) {
+        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+      }
+    } else {
+      for (int r = r0 + ry; r < M; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * N + col);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  }
+  const float4 s = fold16(red, acc, cx, ry);
+  if (ry == 0 && in) *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + col) = s;
+}
+
+// one workgroup per 64 columns; row-lane ry adds partials ry, ry+16, ... and the 16 lanes are folded in order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
+                                                           float* __restrict__ out) {
+  __shared__ float4 red[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = (blockIdx.x * 16 + cx) * 4;
+  const bool in = col < N;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    for (int t = ry; t < S; t += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)t * N + col);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  red[ry][cx] = acc;
-  __syncthreads();
-  if (ry == 0 && col < N) {
-    float4 s = red[0][cx];
-#pragma unroll
-    for (int t = 1; t < 16; ++t) {
-      const float4 v = red[t][cx];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + col) = s;
-  }
-}
-
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
-                                                           float* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int t = 0; t < S; ++t) s += partial[(size_t)t * N + n];
-  out[n] = s;
+  const float4 s = fold16(red, acc, cx, ry);
+  if (ry == 0 && in) *reinterpret_cast<float4*>(out + col) = s;
 }
 
 }  // namespace
@@ -62,12 +89,13 @@ PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* works
     return ptops::check_launch("colsum(memset)");
   }
   PTOPS_REQUIRE(x && workspace, "colsum: null pointer");
-  PTOPS_REQUIRE(N % 4 == 0 && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0,
+  PTOPS_REQUIRE(N % 4 == 0 && (((uintptr_t)x | (uintptr_t)workspace | (uintptr_t)out) & 15) == 0,
                 "colsum: N must be a multiple of 4 and pointers 16-byte aligned");
   const int S = ptops::ceil_div(M, kRowsPerBlock);
+  PTOPS_REQUIRE(S <= 65535, "colsum: M=%d exceeds the grid limit", M);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ptops::ceil_div(N, 64), S), dim3(256), 0, stream, x, M, N,
                      (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream,
                      (const float*)workspace, S, N, out);
   return ptops::check_launch("colsum");
 }

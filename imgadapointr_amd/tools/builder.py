@@ -53,7 +53,12 @@ def build_optimizer(base_model, config):
             (no_decay if param.dim() == 1 or name.endswith('.bias') else decay).append(param)
         groups = [{'params': no_decay, 'weight_decay': 0.},
                   {'params': decay, 'weight_decay': opti_config.kwargs.weight_decay}]
-        return optim.AdamW(groups, **opti_config.kwargs)
+        kwargs = dict(opti_config.kwargs)
+        if all(p.is_cuda for g in groups for p in g['params']) and 'fused' not in kwargs:
+            # one pass over (param, grad, exp_avg, exp_avg_sq) per chunk instead of the ~8 passes of the
+            # for-each implementation: same update rule, 3x less HBM traffic for the 32.5 M parameters
+            kwargs['fused'] = True
+        return optim.AdamW(groups, **kwargs)
     trainable = [p for p in net.parameters() if p.requires_grad]
     if opti_config.type == 'Adam':
         return optim.Adam(trainable, **opti_config.kwargs)
