@@ -56,6 +56,10 @@ def _declare(lib):
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
+        "ptops_layer_norm_max_dim": (c_int, []),
+        "ptops_layer_norm_forward": (c_int, [P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P]),
+        "ptops_layer_norm_backward_workspace_bytes": (c_size, [ctypes.c_longlong, c_int]),
+        "ptops_layer_norm_backward": (c_int, [P] * 5 + [ctypes.c_longlong, c_int, P, P, P, P]),
         "ptops_attention_backward": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
     }
     for name, (res, args) in sig.items():
@@ -74,6 +78,8 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
+    "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_layer_norm_backward_workspace_bytes",
+    "ptops_layer_norm_backward",
 )
 
 
@@ -538,6 +544,60 @@ def colsum(x):
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
         _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
     return out
+
+
+def _scratch(dev, stream, need):
+    """One reusable scratch buffer per (device, stream), grown on demand (stream order makes reuse safe)."""
+    key = (dev.index, stream.cuda_stream)
+    ws = _colsum_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((max(need, 1 << 22),), dtype=torch.uint8, device=dev)
+        _colsum_ws[key] = ws
+    return ws
+
+
+def layer_norm_supported(x, weight, bias):
+    return (x.is_cuda and x.dtype == torch.float32 and weight is not None and bias is not None
+            and x.size(-1) % 4 == 0 and 4 <= x.size(-1) <= 1024 and weight.dtype == torch.float32)
+
+
+def layer_norm_forward(x, weight, bias, eps):
+    """x [rows, C] float32 contiguous -> (y [rows, C], mean [rows], rstd [rows])."""
+    _check(x, "x", torch.float32, 2)
+    _check(weight, "weight", torch.float32, 1)
+    _check(bias, "bias", torch.float32, 1)
+    dev = _same_device(x, weight, bias)
+    rows, C = x.shape
+    if weight.numel() != C or bias.numel() != C:
+        raise ValueError("layer_norm_forward: weight / bias must have C elements")
+    with torch.cuda.device(dev):
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        _call("ptops_layer_norm_forward", _ptr(x), _ptr(weight), _ptr(bias), rows, C, ctypes.c_float(float(eps)),
+              _ptr(y), _ptr(mean), _ptr(rstd), _stream(x))
+    return y, mean, rstd
+
+
+def layer_norm_backward(dy, x, mean, rstd, weight):
+    """-> (dx [rows, C], dgamma_dbeta [2*C])."""
+    _check(dy, "dy", torch.float32, 2)
+    _check(x, "x", torch.float32, 2)
+    _check(mean, "mean", torch.float32, 1)
+    _check(rstd, "rstd", torch.float32, 1)
+    _check(weight, "weight", torch.float32, 1)
+    dev = _same_device(dy, x, mean, rstd, weight)
+    rows, C = x.shape
+    if tuple(dy.shape) != (rows, C) or mean.numel() != rows or rstd.numel() != rows or weight.numel() != C:
+        raise ValueError("layer_norm_backward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        ws = _scratch(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16))
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        _call("ptops_layer_norm_backward", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(weight), rows, C, _ptr(dx),
+              _ptr(dgb), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+    return dx, dgb
 
 
 def edge_select(P, R, idx, take_max):

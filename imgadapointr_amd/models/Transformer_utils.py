@@ -94,6 +94,36 @@ class Linear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
+FAST_LAYER_NORM = True
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = x.contiguous().view(-1, x.size(-1))
+        y, mean, rstd = _native.layer_norm_forward(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        C = x2.size(1)
+        dx, dgb = _native.layer_norm_backward(gy.contiguous().view(-1, C), x2, mean, rstd, weight)
+        return dx.view(gy.shape), dgb[:C], dgb[C:], None
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state-dict keys) on the library's streaming kernels: one pass forward,
+    one pass backward (dx and the dgamma / dbeta partials together)."""
+
+    def forward(self, x):
+        if (FAST_LAYER_NORM and len(self.normalized_shape) == 1 and _native.backend_for_testing() is None
+                and _native.layer_norm_supported(x, self.weight, self.bias) and x.numel() >= 1 << 16):
+            return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+
+
 # ------------------------------------------------------------------------------ functional
 def knn_idx(nsample, xyz, new_xyz):
     """int32 [B,S,nsample] neighbour indices, ordered by (distance, index).  No gradient."""

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import _native
 from ..pointnet2_ops import pointnet2_utils
-from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerScale, Linear, Mlp,
+from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerNorm, LayerScale, Linear, Mlp,
                                 knn_idx, linear_on_broadcast_concat)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
@@ -67,7 +67,7 @@ class SelfAttnBlockApi(nn.Module):
     (base_blocks.py:14-109)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., init_values=None,
-                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, block_style='attn-deform',
+                 drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm, block_style='attn-deform',
                  combine_style='concat', k=10, n_group=2):
         super().__init__()
         self.combine_style = combine_style
@@ -123,7 +123,7 @@ class CrossAttnBlockApi(nn.Module):
     graph branch) -> cross attention (same options) -> MLP  (base_blocks.py:112-313)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., init_values=None,
-                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  self_attn_block_style='attn-deform', self_attn_combine_style='concat',
                  cross_attn_block_style='attn-deform', cross_attn_combine_style='concat', k=10, n_group=2):
         super().__init__()
@@ -247,7 +247,7 @@ class TransformerEncoder(nn.Module):
     """Stack of SelfAttnBlockApi; the kNN graph is computed once per forward (base_blocks.py:316-334)."""
 
     def __init__(self, embed_dim=256, depth=4, num_heads=4, mlp_ratio=4., qkv_bias=False, init_values=None,
-                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  block_style_list=['attn-deform'], combine_style='concat', k=10, n_group=2):
         super().__init__()
         self.k = k
@@ -271,7 +271,7 @@ class TransformerDecoder(nn.Module):
     """Stack of CrossAttnBlockApi (base_blocks.py:337-367)."""
 
     def __init__(self, embed_dim=256, depth=4, num_heads=4, mlp_ratio=4., qkv_bias=False, init_values=None,
-                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., act_layer=nn.GELU, norm_layer=LayerNorm,
                  self_attn_block_style_list=['attn-deform'], self_attn_combine_style='concat',
                  cross_attn_block_style_list=['attn-deform'], cross_attn_combine_style='concat', k=10, n_group=2):
         super().__init__()
@@ -305,7 +305,7 @@ class PointTransformerEncoder(nn.Module):
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=None, act_layer=None,
                  block_style_list=['attn-deform'], combine_style='concat', k=10, n_group=2):
         super().__init__()
-        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        norm_layer = norm_layer or partial(LayerNorm, eps=1e-6)
         act_layer = act_layer or nn.GELU
         self.num_features = self.embed_dim = embed_dim
         self.pos_drop = nn.Dropout(p=drop_rate)
@@ -331,7 +331,7 @@ class PointTransformerDecoder(nn.Module):
                  self_attn_block_style_list=['attn-deform'], self_attn_combine_style='concat',
                  cross_attn_block_style_list=['attn-deform'], cross_attn_combine_style='concat', k=10, n_group=2):
         super().__init__()
-        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        norm_layer = norm_layer or partial(LayerNorm, eps=1e-6)
         act_layer = act_layer or nn.GELU
         self.num_features = self.embed_dim = embed_dim
         self.pos_drop = nn.Dropout(p=drop_rate)

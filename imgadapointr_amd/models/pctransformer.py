@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .AdaPoinTr import PCTransformer as _PointTrunk
 from .image_encoders import ResNet18
+from .Transformer_utils import LayerNorm
 
 
 class PCTransformer(_PointTrunk):
@@ -46,7 +47,7 @@ class PCTransformer(_PointTrunk):
         names = [('cross_attn', 1), ('self_attn', 1), ('cross_attn', 2), ('self_attn', 2), ('cross_attn', 3)]
         for i, (kind, n) in enumerate(names, start=1):
             setattr(self, f'{kind}_{tag}{n}', nn.MultiheadAttention(self.img_dim, 8))
-            setattr(self, f'layer_norm_{tag}{i}', nn.LayerNorm(self.img_dim))
+            setattr(self, f'layer_norm_{tag}{i}', LayerNorm(self.img_dim))
 
     def _fuse(self, x, ctx, tag):
         """x [N,B,C] tokens, ctx [M,B,C] context (sequence-first, as nn.MultiheadAttention expects)."""

@@ -415,3 +415,45 @@ def test_fused_edge_conv_function_vs_float64(native, B, C, Nq, Nk, k, G):
         tol = 1e-4 * max(1.0, b.abs().max().item())
         bad = ((a.double() - b).abs() > tol).float().mean().item()
         assert bad <= 1e-4, (name, bad, (a.double() - b).abs().max().item())
+
+
+@pytest.mark.parametrize("rows,C", [(18432, 384), (8192, 384), (1000, 96), (515, 1024), (3, 8), (4096, 640)])
+def test_layer_norm_forward_and_backward(native, rows, C):
+    """Streaming LayerNorm kernels vs float64 torch: y, dx, dgamma, dbeta."""
+    torch.manual_seed(rows + C)
+    x = (torch.randn(rows, C, device="cuda") * 2 + 0.7).requires_grad_(True)
+    w = (torch.randn(C, device="cuda") * 0.5 + 1).requires_grad_(True)
+    b = torch.randn(C, device="cuda").requires_grad_(True)
+    go = torch.randn(rows, C, device="cuda") + 0.1
+    y, mean, rstd = native.layer_norm_forward(x.detach(), w.detach(), b.detach(), 1e-5)
+    dx, dgb = native.layer_norm_backward(go, x.detach(), mean, rstd, w.detach())
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.layer_norm(x64, (C,), w64, b64, 1e-5)
+    gx, gw, gb = torch.autograd.grad(ref, (x64, w64, b64), go.double())
+    assert (y.double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+    assert (dx.double() - gx).abs().max().item() < 1e-5 * max(1.0, gx.abs().max().item())
+    assert (dgb[:C].double() - gw).abs().max().item() < 2e-5 * max(1.0, gw.abs().max().item())
+    assert (dgb[C:].double() - gb).abs().max().item() < 2e-5 * max(1.0, gb.abs().max().item())
+    # deterministic
+    dx2, dgb2 = native.layer_norm_backward(go, x.detach(), mean, rstd, w.detach())
+    assert torch.equal(dx, dx2) and torch.equal(dgb, dgb2)
+
+
+def test_layer_norm_module_matches_torch(native):
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(3)
+    ln = TU.LayerNorm(384, eps=1e-6).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0.0, 0.2)
+    x = torch.randn(32, 576, 384, device="cuda", requires_grad=True)
+    res = {}
+    for fast in (True, False):
+        TU.FAST_LAYER_NORM = fast
+        y = ln(x.transpose(0, 1).transpose(0, 1))          # a non-trivial view of x
+        g = torch.autograd.grad(y.square().sum(), [x, ln.weight, ln.bias])
+        res[fast] = [y.detach()] + [t.detach() for t in g]
+    TU.FAST_LAYER_NORM = True
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+    assert sorted(ln.state_dict().keys()) == ["bias", "weight"]
