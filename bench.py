@@ -183,7 +183,9 @@ def main():
     torch.manual_seed(0)                     # identical weights on every rank
     model = build_model_from_cfg(cfg.model).to(device)
     model.train()
-    wrapped = FlatDDP(model) if world > 1 else model
+    # PTOPS_BENCH_FORCE_DDP=1 wraps the model at N=1 too (hooks + bucket packing, no collective): a way to see
+    # the data-parallel bookkeeping overhead on a one-GPU box.  Never the default.
+    wrapped = FlatDDP(model) if (world > 1 or os.environ.get("PTOPS_BENCH_FORCE_DDP") == "1") else model
     optimizer = builder.build_optimizer(wrapped, cfg)
     step = TrainStep(wrapped, optimizer, getattr(cfg, "grad_norm_clip", 10), 1)
 

@@ -36,8 +36,15 @@ def main():
             step(partial, gt)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=50, max_name_column_width=70))
-    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=90,
-                                                             max_name_column_width=50, max_shapes_column_width=90))
+    # the small aten ops (everything but the GEMMs), grouped by input shape, per step
+    skip = ("aten::mm", "aten::addmm", "aten::bmm", "aten::matmul", "aten::linear")
+    rows = [e for e in prof.key_averages(group_by_input_shape=True)
+            if e.key.startswith("aten::") and e.key not in skip and getattr(e, "self_device_time_total", 0) > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    tot = sum(e.self_device_time_total for e in rows)
+    print(f"\nnon-GEMM aten ops: {tot / 3e3:.3f} ms per step")
+    for e in rows[:90]:
+        print(f"{e.self_device_time_total / 3e3:8.3f} ms  x{e.count / 3:6.1f}  {e.key:38s} {str(e.input_shapes)[:150]}")
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ class TrainStep:
     def __call__(self, partial, gt, extra=(), epoch=0):
         ret = self.model(partial, *extra)
         sparse_loss, dense_loss = self.net.get_loss(ret, gt, epoch)
+        if self.ddp is not None:            # average only the backward that completes an update
+            self.ddp.set_sync(self._num_iter + 1 == self.step_per_update)
         (sparse_loss + dense_loss).backward()
         self._num_iter += 1
         if self._num_iter == self.step_per_update:

@@ -2,18 +2,22 @@
 
 Replaces the reference's `nn.parallel.DistributedDataParallel(..., find_unused_parameters=True)`
 (tools/runner.py:83-93).  Design for MI355X's point-to-point xGMI fabric:
-  * gradients accumulate IN PLACE into a few large contiguous fp32 buckets (parameters' `.grad`
-    are views into them), so a collective moves one large message per bucket instead of many
-    25 MB ones, and no flatten/unflatten copies exist;
-  * buckets are filled in reverse parameter order (the order backward produces gradients); a
-    bucket's all-reduce is launched asynchronously from the autograd hook of its last gradient,
-    overlapping with the rest of backward;
+  * gradients are averaged in a few large contiguous fp32 buckets, so a collective moves one large
+    message per bucket instead of many 25 MB ones;
+  * buckets are laid out in reverse parameter order (the order backward produces gradients).  During
+    backward every parameter's `.grad` is the tensor autograd produced (no accumulate-into-zero kernels:
+    `.grad` is None when backward starts); when the LAST gradient of a bucket arrives, its hook packs
+    the bucket with one multi-tensor copy, launches the bucket's all-reduce asynchronously (it overlaps
+    the rest of backward) and re-points the `.grad`s at views of the bucket, so nothing is unpacked;
   * parameters that never receive a gradient (AdaPoinTr: `base_model.encoder.norm.*`,
     `base_model.query_ranking.*`) are discovered on the first step and left out of
     the buckets — there is no per-iteration unused-parameter bitmap all-reduce; their `.grad`
     stays None so the optimizer skips them exactly as it does under the reference's DDP;
   * `finalize()` (called by the runner after backward) waits for the collectives, launches any
-    bucket whose hooks did not all fire (rare control-flow change) and divides by world size.
+    bucket whose hooks did not all fire (rare control-flow change; missing gradients count as zero)
+    and divides by world size;
+  * `set_sync(False)` turns the averaging off for a backward (gradient accumulation over several
+    micro-batches: only the last one is averaged, as with DDP's `no_sync`).
 """
 import torch
 import torch.distributed as dist
@@ -27,10 +31,13 @@ class FlatDDP(nn.Module):
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
-        self._buckets = None       # list of dict(flat, params, pending, handle)
+        self._buckets = None       # list of dict(flat, params, views, pending, handle, packed)
         self._param_bucket = {}
         self._hooks = []
         self._discovered = False
+        self._sync = True
+        # RCCL averages inside the collective; gloo (CPU tests) only sums, so divide afterwards there
+        self._avg_in_collective = (self.world_size > 1 and dist.get_backend(process_group) == "nccl")
         # identical start: rank 0's parameters and buffers everywhere (as DDP does at wrap time)
         if self.world_size > 1:
             for t in list(module.parameters()) + list(module.buffers()):
@@ -38,6 +45,9 @@ class FlatDDP(nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def set_sync(self, sync):
+        self._sync = bool(sync)
 
     # ------------------------------------------------------------------ bucket construction
     def _build_buckets(self, used_params):
@@ -55,71 +65,88 @@ class FlatDDP(nn.Module):
         for plist in buckets:
             n = sum(p.numel() for p in plist)
             flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-            b = dict(flat=flat, params=plist, pending=len(plist), handle=None, views=[])
+            b = dict(flat=flat, params=plist, pending=len(plist), handle=None, views=[], packed=False)
             off = 0
             for p in plist:
-                v = flat[off:off + p.numel()].view_as(p)
-                if p.grad is not None:
-                    v.copy_(p.grad)
-                p.grad = v
-                b["views"].append(v)
+                b["views"].append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
                 self._param_bucket[p] = b
             self._buckets.append(b)
         for p in self._param_bucket:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def _pack(self, b):
+        """Gather the bucket's gradients into its flat buffer (one multi-tensor copy) and make the
+        `.grad`s views of it; a parameter without a gradient contributes zeros."""
+        src, dst = [], []
+        for p, v in zip(b["params"], b["views"]):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        b["packed"] = True
+
+    def _launch(self, b, async_op=True):
+        self._pack(b)
+        if self.world_size > 1:
+            op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+            b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.process_group, async_op=async_op)
+
     def _on_grad(self, p):
+        if not self._sync:
+            return
         b = self._param_bucket.get(p)
         if b is None:
             return
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world_size > 1:
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.process_group,
-                                          async_op=True)
+        if b["pending"] == 0:
+            self._launch(b)
 
     # ------------------------------------------------------------------------- step protocol
     def zero_grad(self, set_to_none=True):
-        """Zero the buckets and re-attach the `.grad` views; unused parameters get grad None."""
-        if self._buckets is None:
-            self.module.zero_grad(set_to_none=True)
-            return
-        for b in self._buckets:
-            b["flat"].zero_()
+        """Drop all gradients (`.grad = None`: backward then hands its tensors over without an add)."""
+        for p in self.module.parameters():
+            p.grad = None
+        for b in (self._buckets or []):
             b["pending"] = len(b["params"])
             b["handle"] = None
-            for p, v in zip(b["params"], b["views"]):
-                p.grad = v
-        for p in self.module.parameters():
-            if p not in self._param_bucket:
-                p.grad = None
+            b["packed"] = False
 
     def finalize(self):
-        """Call once after backward: completes the gradient averaging for this step."""
+        """Call once after the (last) backward of a step: completes the gradient averaging."""
         if not self._discovered:
             # First step: learn which parameters take part, average them without overlap.
             used = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
             self._build_buckets(used)
             self._discovered = True
-            if self.world_size > 1:
-                for b in self._buckets:
-                    dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.process_group)
+            for b in self._buckets:
+                self._launch(b, async_op=False)
+                if self.world_size > 1 and not self._avg_in_collective:
                     b["flat"].div_(self.world_size)
             return
+        for b in self._buckets:
+            if not b["packed"]:          # some hook did not fire, or averaging was off during backward
+                self._launch(b)
         if self.world_size > 1:
             for b in self._buckets:
-                if b["handle"] is None:  # some hook did not fire: reduce what is there (zeros included)
-                    b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.process_group,
-                                                  async_op=True)
-            for b in self._buckets:
-                b["handle"].wait()
-                b["flat"].div_(self.world_size)
+                if b["handle"] is not None:
+                    b["handle"].wait()
+                if not self._avg_in_collective:
+                    b["flat"].div_(self.world_size)
             # a parameter outside the buckets that suddenly received a gradient
             for p in self.module.parameters():
                 if p.requires_grad and p.grad is not None and p not in self._param_bucket:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.process_group)
                     p.grad.div_(self.world_size)
-        # parameters inside a bucket whose hook did not fire keep a zero gradient (DDP semantics)
+
+    def unused_parameter_names(self):
+        """Names of the trainable parameters that received no gradient on the first step."""
+        return [n for n, p in self.module.named_parameters() if p.requires_grad and p not in self._param_bucket]
 
     def grad_buffers(self):
         return [b["flat"] for b in (self._buckets or [])]
