@@ -89,7 +89,10 @@ class ChamferProbe:
                 pmc = json.load(fh).get("derived", {})
             traffic = pmc.get("hbm_traffic_bytes_corrected")
         return {
-            "bound": "valu-fp32", "kernel": "Chamfer 16384x16384 launch (sort + two pruned sweeps; exact nearest neighbours, both directions)",
+            "bound": "valu-fp32",
+            "kernel": "Chamfer 16384x16384 forward launch (exact nearest neighbours, both directions; per direction the "
+                      "adaptive policy ran: " + "/".join({0: "auto", 1: "brute-force chamfer_nn_kernel", 2: "pruned sweep"}[a]
+                                                         for a in _native.chamfer_algorithm_log.get((B, n, m), (0, 0))) + ")",
             "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
             "traffic_source": "profiles/round1/chamfer_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",

@@ -20,6 +20,8 @@ FAMILIES = [
     ("ptops: edge-conv", r"edge_select|edge_scatter|edge_group"),
     ("ptops: gather/index", r"gather_|index_points"),
     ("ptops: attention fwd", r"attn_fwd_kernel"),
+    ("ptops: attention bwd", r"attn_bwd_"),
+    ("ptops: layernorm", r"ln_fwd_kernel|ln_bwd_kernel"),
     ("ptops: colsum", r"colsum_"),
     ("attention bwd (aten)", r"fmha|attention|AttentionBackward|efficient_attention"),
     ("GEMM (hipBLASLt/rocBLAS/CK)", r"^Cijk_|gemm|Gemm"),

@@ -201,6 +201,9 @@ class _ChamferPolicy:
 _chamfer_policy = _ChamferPolicy()
 
 
+chamfer_algorithm_log = {}   # (B, n, m) -> algorithms of the most recent launch, for logs and bench.py
+
+
 def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
     """chamfer.forward (extensions/chamfer_dist/chamfer_cuda.cpp:22-25).  `algorithm`: CHAMFER_AUTO
     (adaptive per direction, see _ChamferPolicy), CHAMFER_BRUTE, CHAMFER_SWEEP, or a pair of those for
@@ -236,6 +239,7 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
               _ptr(stats) if stats is not None else None, _stream(xyz1))
         if stats is not None:
             _chamfer_policy.record(st, stats)
+        chamfer_algorithm_log[(B, n, m)] = tuple(int(a) for a in algos)
     return dist1, dist2, idx1, idx2
 
 
