@@ -53,6 +53,9 @@ def _declare(lib):
         "ptops_edge_select_blocks": (c_int, [c_int]),
         "ptops_edge_select": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P, P, P, P]),
         "ptops_edge_scatter": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P]),
+        "ptops_edge_norm_forward": (c_int, [P] * 4 + [c_int] * 6 + [ctypes.c_float, ctypes.c_float, P, P, P]),
+        "ptops_edge_norm_backward_workspace_bytes": (c_size, [c_int] * 4),
+        "ptops_edge_norm_backward": (c_int, [P] * 10 + [c_int] * 6 + [ctypes.c_float] + [P] * 5),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
@@ -78,6 +81,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
+    "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_layer_norm_backward_workspace_bytes",
     "ptops_layer_norm_backward",
 )
@@ -625,6 +629,45 @@ def edge_select(P, R, idx, take_max):
         _call("ptops_edge_select", _ptr(P), _ptr(R), _ptr(idx), _ptr(take_max), B, C, Nk, Nq, k, _ptr(ysel),
               _ptr(nsel), _ptr(ysum), _ptr(partial), _stream(P))
     return ysel, nsel, ysum, partial
+
+
+def edge_norm_forward(ysel, partial, gamma, beta, groups, k, eps, slope):
+    """ysel [B,C,Nq], partial [B,C,nblk,2] (from edge_select) -> (out [B,C,Nq], mean_rstd [B,groups,2])."""
+    _check(ysel, "ysel", torch.float32, 3)
+    _check(partial, "partial", torch.float32, 4)
+    _check(gamma, "gamma", torch.float32, 1)
+    _check(beta, "beta", torch.float32, 1)
+    dev = _same_device(ysel, partial, gamma, beta)
+    B, C, Nq = ysel.shape
+    with torch.cuda.device(dev):
+        out = torch.empty_like(ysel)
+        mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+        _call("ptops_edge_norm_forward", _ptr(ysel), _ptr(partial), _ptr(gamma), _ptr(beta), B, C, Nq, partial.size(2),
+              int(groups), int(k), ctypes.c_float(float(eps)), ctypes.c_float(float(slope)), _ptr(out), _ptr(mean_rstd),
+              _stream(ysel))
+    return out, mean_rstd
+
+
+def edge_norm_backward(grad_out, ysel, ysum, P, R, idx, nsel, gamma, beta, mean_rstd, slope):
+    """-> (dP [B,C,Nk], dR [B,C,Nq], sums [B,C,2] = per (b,c) {sum dz, sum dz*yhat})."""
+    for t, name in ((grad_out, "grad_out"), (ysel, "ysel"), (ysum, "ysum"), (P, "P"), (R, "R")):
+        _check(t, name, torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    _check(nsel, "nsel", torch.int32, 3)
+    dev = _same_device(grad_out, ysel, ysum, P, R, idx, nsel, gamma, beta, mean_rstd)
+    B, C, Nq = ysel.shape
+    Nk, k, groups = P.size(2), idx.size(2), mean_rstd.size(1)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        dP = torch.empty_like(P)
+        dR = torch.empty_like(R)
+        sums = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty((load().ptops_edge_norm_backward_workspace_bytes(B, C, Nq, groups) // 4 + 4,),
+                         dtype=torch.float32, device=dev)
+        _call("ptops_edge_norm_backward", _ptr(grad_out), _ptr(ysel), _ptr(ysum), _ptr(P), _ptr(R), _ptr(idx), _ptr(nsel),
+              _ptr(gamma), _ptr(beta), _ptr(mean_rstd), B, C, Nk, Nq, k, groups, ctypes.c_float(float(slope)), _ptr(dP),
+              _ptr(dR), _ptr(sums), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+    return dP, dR, sums
 
 
 def edge_scatter(dense, sel, idx, nsel, Nk):

@@ -124,6 +124,184 @@ __global__ __launch_bounds__(kTPB) void edge_scatter_kernel(
   }
 }
 
+
+// ---- GroupNorm statistics, affine + LeakyReLU, and the element-wise parts of the backward --------------------
+// All tensors here are [B, C, Nq] (<= 8 MB): these kernels exist to replace ~35 tiny PyTorch launches per stage.
+
+__device__ __forceinline__ double block_sum_double(double v, double* red) {
+  // fixed-order tree over 256 threads
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// one workgroup per (b, group): mean / rstd of all edge values from the per-workgroup partials of edge_select
+__global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ partial, int C, int G, int nblk,
+                                                         double M, float eps, float* __restrict__ mean_rstd) {
+  __shared__ double red[256];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const float* base = partial + ((size_t)b * C + (size_t)g * cpg) * nblk * 2;
+  const int n = cpg * nblk;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    s1 += (double)base[2 * t];
+    s2 += (double)base[2 * t + 1];
+  }
+  s1 = block_sum_double(s1, red);
+  s2 = block_sum_double(s2, red);
+  if (threadIdx.x == 0) {
+    const double mu = s1 / M;
+    double var = s2 / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[2 * blockIdx.x] = (float)mu;
+    mean_rstd[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+__device__ __forceinline__ float edge_z(float y, float mu, float rs, float ga, float be, float* yhat) {
+  *yhat = (y - mu) * rs;
+  return fmaf(*yhat, ga, be);
+}
+
+// out = LeakyReLU(gamma * (ysel - mean) * rstd + beta)
+__global__ __launch_bounds__(256) void edge_affine_kernel(const float* __restrict__ ysel, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ mean_rstd, int C, int G, int Nq,
+                                                          float slope, float* __restrict__ out) {
+  const int bc = blockIdx.y, b = bc / C, c = bc % C;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Nq) return;
+  const int g = c / (C / G);
+  const float mu = mean_rstd[2 * (b * G + g)], rs = mean_rstd[2 * (b * G + g) + 1];
+  float yh;
+  const float z = edge_z(ysel[(size_t)bc * Nq + q], mu, rs, gamma[c], beta[c], &yh);
+  out[(size_t)bc * Nq + q] = z > 0.0f ? z : z * slope;
+}
+
+// per (b, c): sum_q dz and sum_q dz * yhat, dz = go * LeakyReLU'(z)
+__global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __restrict__ go, const float* __restrict__ ysel,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ mean_rstd, int C, int G, int Nq,
+                                                              float slope, float* __restrict__ sums) {
+  __shared__ double red[256];
+  const int bc = blockIdx.x, b = bc / C, c = bc % C;
+  const int g = c / (C / G);
+  const float mu = mean_rstd[2 * (b * G + g)], rs = mean_rstd[2 * (b * G + g) + 1];
+  const float ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int q = threadIdx.x; q < Nq; q += 256) {
+    float yh;
+    const float z = edge_z(ysel[(size_t)bc * Nq + q], mu, rs, ga, be, &yh);
+    const float dz = go[(size_t)bc * Nq + q] * (z > 0.0f ? 1.0f : slope);
+    s1 += (double)dz;
+    s2 += (double)dz * (double)yh;
+  }
+  s1 = block_sum_double(s1, red);
+  s2 = block_sum_double(s2, red);
+  if (threadIdx.x == 0) {
+    sums[2 * bc] = (float)s1;
+    sums[2 * bc + 1] = (float)s2;
+  }
+}
+
+// per (b, group): the two coefficients of dy_e = [selected] S + A + Bc * y_e
+__global__ __launch_bounds__(64) void edge_bwd_group_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_rstd, int total, int C,
+                                                            int G, double M, float* __restrict__ ab) {
+  const int bg = blockIdx.x * 64 + threadIdx.x;
+  if (bg >= total) return;  // total = B * G
+  const int b = bg / G, g = bg % G;
+  const int cpg = C / G;
+  double m1 = 0.0, m2 = 0.0;
+  for (int t = 0; t < cpg; ++t) {
+    const int c = g * cpg + t;
+    m1 += (double)gamma[c] * (double)sums[2 * ((size_t)b * C + c)];
+    m2 += (double)gamma[c] * (double)sums[2 * ((size_t)b * C + c) + 1];
+  }
+  m1 /= M;
+  m2 /= M;
+  const double mu = mean_rstd[2 * bg], rs = mean_rstd[2 * bg + 1];
+  const double Bc = -(rs * rs) * m2;
+  ab[2 * bg] = (float)(-rs * m1 - Bc * mu);
+  ab[2 * bg + 1] = (float)Bc;
+}
+
+// S = rstd * gamma * dz (selected-edge term) and dR = S + k A + Bc ysum
+__global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __restrict__ go, const float* __restrict__ ysel,
+                                                             const float* __restrict__ ysum,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ ab, int C, int G, int Nq, int k,
+                                                             float slope, float* __restrict__ S, float* __restrict__ dR) {
+  const int bc = blockIdx.y, b = bc / C, c = bc % C;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Nq) return;
+  const int g = c / (C / G);
+  const float mu = mean_rstd[2 * (b * G + g)], rs = mean_rstd[2 * (b * G + g) + 1];
+  const float A = ab[2 * (b * G + g)], Bc = ab[2 * (b * G + g) + 1];
+  const size_t o = (size_t)bc * Nq + q;
+  float yh;
+  const float z = edge_z(ysel[o], mu, rs, gamma[c], beta[c], &yh);
+  const float dz = go[o] * (z > 0.0f ? 1.0f : slope);
+  const float s = rs * gamma[c] * dz;
+  S[o] = s;
+  dR[o] = s + (float)k * A + Bc * ysum[o];
+}
+
+// dP[c, n] = sum_{e -> n} (A + Bc y_e) + sum_{selected e -> n} S[c, q_e]
+//          = cnt[n] (A + Bc P[c, n]) + Bc sum_{e -> n} R[c, q_e] + sum_{selected e -> n} S[c, q_e]
+template <int CT>
+__global__ __launch_bounds__(kTPB) void edge_scatter_dp_kernel(
+    const float* __restrict__ P, const float* __restrict__ R, const float* __restrict__ S,
+    const int32_t* __restrict__ idx, const int32_t* __restrict__ nsel, const float* __restrict__ ab, int C, int G,
+    int Nk, int Nq, int k, float* __restrict__ dP) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [CT + 1][Nk]: CT channels + the in-degree row
+  const int b = blockIdx.y, c0 = blockIdx.x * CT;
+  for (int t = threadIdx.x; t < (CT + 1) * Nk; t += kTPB) tile[t] = 0.0f;
+  __syncthreads();
+  const int32_t* ib = idx + (size_t)b * Nq * k;
+  float* cnt = tile + CT * Nk;
+  const int cpg = C / G;
+  for (int q = threadIdx.x; q < Nq; q += kTPB) {
+    int id[kMaxK];
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j) id[j] = j < k ? ib[(size_t)q * k + j] : 0;
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j)
+      if (j < k) atomicAdd(&cnt[id[j]], 1.0f);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = c0 + ct;
+      if (c >= C) break;
+      const size_t o = ((size_t)b * C + c) * Nq + q;
+      const float dv = ab[2 * (b * G + c / cpg) + 1] * R[o];
+#pragma unroll
+      for (int j = 0; j < kMaxK; ++j)
+        if (j < k) atomicAdd(&tile[ct * Nk + id[j]], dv);
+      atomicAdd(&tile[ct * Nk + nsel[o]], S[o]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < CT * Nk; t += kTPB) {
+    const int ct = t / Nk, n = t - ct * Nk;
+    const int c = c0 + ct;
+    if (c < C) {
+      const float A = ab[2 * (b * G + c / cpg)], Bc = ab[2 * (b * G + c / cpg) + 1];
+      const size_t o = ((size_t)b * C + c) * Nk + n;
+      dP[o] = tile[t] + cnt[n] * (A + Bc * P[o]);
+    }
+  }
+}
+
 }  // namespace
 
 PTOPS_API int ptops_edge_select_blocks(int Nq) { return ptops::ceil_div(Nq, kTPB); }
@@ -160,4 +338,62 @@ PTOPS_API int ptops_edge_scatter(const float* dense, const float* sel, const int
     default: hipLaunchKernelGGL(edge_scatter_kernel<1>, grid, dim3(kTPB), lds, stream, dense, sel, idx, nsel, C, Nk, Nq, k, T); break;
   }
   return ptops::check_launch("edge_scatter_kernel");
+}
+
+PTOPS_API int ptops_edge_norm_forward(const float* ysel, const float* partial, const float* gamma, const float* beta,
+                                      int B, int C, int Nq, int nblk, int groups, int k, float eps, float slope,
+                                      float* out, float* mean_rstd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && C >= 1 && Nq >= 1 && nblk >= 1 && groups >= 1 && C % groups == 0 && k >= 1,
+                "edge_norm_forward: bad size");
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(ysel && partial && gamma && beta && out && mean_rstd, "edge_norm_forward: null pointer");
+  PTOPS_REQUIRE((long long)B * C <= 65535, "edge_norm_forward: B*C exceeds grid limit");
+  const double M = (double)(C / groups) * Nq * k;
+  hipLaunchKernelGGL(edge_stats_kernel, dim3(B * groups), dim3(256), 0, stream, partial, C, groups, nblk, M, eps,
+                     mean_rstd);
+  hipLaunchKernelGGL(edge_affine_kernel, dim3(ptops::ceil_div(Nq, 256), B * C), dim3(256), 0, stream, ysel, gamma, beta,
+                     mean_rstd, C, groups, Nq, slope, out);
+  return ptops::check_launch("edge_norm_forward");
+}
+
+PTOPS_API size_t ptops_edge_norm_backward_workspace_bytes(int B, int C, int Nq, int groups) {
+  if (B <= 0 || C <= 0 || Nq <= 0 || groups <= 0) return 0;
+  return sizeof(float) * ((size_t)B * C * Nq + 2 * (size_t)B * groups + 4);
+}
+
+PTOPS_API int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const float* ysum, const float* P,
+                                       const float* R, const int32_t* idx, const int32_t* nsel, const float* gamma,
+                                       const float* beta, const float* mean_rstd, int B, int C, int Nk, int Nq, int k,
+                                       int groups, float slope, float* dP, float* dR, float* sums, void* workspace,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && C >= 1 && Nk >= 1 && Nq >= 1 && k >= 1 && k <= kMaxK && groups >= 1 && C % groups == 0,
+                "edge_norm_backward: bad size (k <= %d)", kMaxK);
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(grad_out && ysel && ysum && P && R && idx && nsel && gamma && beta && mean_rstd && dP && dR && sums &&
+                    workspace,
+                "edge_norm_backward: null pointer");
+  PTOPS_REQUIRE((long long)B * C <= 65535, "edge_norm_backward: B*C exceeds grid limit");
+  PTOPS_REQUIRE((size_t)2 * Nk * sizeof(float) <= 64 * 1024, "edge_norm_backward: Nk=%d does not fit an LDS tile", Nk);
+  float* S = (float*)workspace;
+  float* ab = S + (size_t)B * C * Nq;
+  const double M = (double)(C / groups) * Nq * k;
+  hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, stream, grad_out, ysel, gamma, beta, mean_rstd, C,
+                     groups, Nq, slope, sums);
+  hipLaunchKernelGGL(edge_bwd_group_kernel, dim3(ptops::ceil_div(B * groups, 64)), dim3(64), 0, stream, sums, gamma,
+                     mean_rstd, B * groups, C, groups, M, ab);
+  hipLaunchKernelGGL(edge_bwd_apply_kernel, dim3(ptops::ceil_div(Nq, 256), B * C), dim3(256), 0, stream, grad_out, ysel,
+                     ysum, gamma, beta, mean_rstd, ab, C, groups, Nq, k, slope, S, dR);
+  int CT = 8;
+  while (CT > 1 && ((long long)B * ptops::ceil_div(C, CT) < 512 || (size_t)(CT + 1) * Nk * 4 > 64 * 1024)) CT >>= 1;
+  dim3 grid(ptops::ceil_div(C, CT), B);
+  const size_t lds = (size_t)(CT + 1) * Nk * sizeof(float);
+  switch (CT) {
+    case 8: hipLaunchKernelGGL(edge_scatter_dp_kernel<8>, grid, dim3(kTPB), lds, stream, P, R, S, idx, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+    case 4: hipLaunchKernelGGL(edge_scatter_dp_kernel<4>, grid, dim3(kTPB), lds, stream, P, R, S, idx, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+    case 2: hipLaunchKernelGGL(edge_scatter_dp_kernel<2>, grid, dim3(kTPB), lds, stream, P, R, S, idx, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+    default: hipLaunchKernelGGL(edge_scatter_dp_kernel<1>, grid, dim3(kTPB), lds, stream, P, R, S, idx, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+  }
+  return ptops::check_launch("edge_norm_backward");
 }

@@ -392,50 +392,24 @@ class _FusedEdgeConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, P, R, idx, gamma, beta, groups, eps, slope):
-        B, C, Nk = P.shape
-        Nq, k = idx.shape[1], idx.shape[2]
+        P, R = P.contiguous(), R.contiguous()
+        k = idx.shape[2]
         take_max = (gamma >= 0).to(torch.uint8)
-        ysel, nsel, ysum, partial = _native.edge_select(P.contiguous(), R.contiguous(), idx, take_max)
-        M = (C // groups) * Nq * k
-        sums = partial.double().view(B, groups, -1, 2).sum(dim=2)             # [B,G,2], fixed order
-        mean = sums[..., 0] / M
-        var = (sums[..., 1] / M - mean * mean).clamp_min(0.0)
-        rstd = (var + eps).rsqrt()
-        cpg = C // groups
-        mean_c = mean.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)     # [B,C,1]
-        rstd_c = rstd.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)
-        yhat = (ysel - mean_c) * rstd_c
-        z = yhat * gamma.view(1, C, 1) + beta.view(1, C, 1)
-        out = torch.nn.functional.leaky_relu(z, slope)
-        ctx.save_for_backward(P, R, idx, gamma, nsel, ysum, yhat, z, mean_c, rstd_c)
-        ctx.cfg = (groups, slope, M, k)
+        ysel, nsel, ysum, partial = _native.edge_select(P, R, idx, take_max)
+        out, mean_rstd = _native.edge_norm_forward(ysel, partial, gamma, beta, groups, k, eps, slope)
+        ctx.save_for_backward(P, R, idx, gamma, beta, nsel, ysum, ysel, mean_rstd)
+        ctx.slope = slope
         return out
 
     @staticmethod
     def backward(ctx, go):
-        P, R, idx, gamma, nsel, ysum, yhat, z, mean_c, rstd_c = ctx.saved_tensors
-        groups, slope, M, k = ctx.cfg
-        B, C, Nk = P.shape
-        cpg = C // groups
-        dz = go * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
-        dgamma = (dz * yhat).sum(dim=(0, 2))
-        dbeta = dz.sum(dim=(0, 2))
-        gdz = dz * gamma.view(1, C, 1)                                         # d/d(yhat) on the selected edges
-
-        def group_mean(t):                                                     # [B,C,Nq] -> [B,C,1], mean over the group
-            m = t.double().reshape(B, groups, -1).sum(dim=2) / M
-            return m.float().repeat_interleave(cpg, dim=1).unsqueeze(-1)
-
-        m1, m2 = group_mean(gdz), group_mean(gdz * yhat)
-        S = rstd_c * gdz                                                       # selected-edge term
-        Bg = -(rstd_c * rstd_c) * m2                                           # dy_e = [sel] S + Ag + Bg * y_e
-        Ag = -rstd_c * m1 - Bg * mean_c
-        dR = S + k * Ag + Bg * ysum
-        T = _native.edge_scatter((Bg * R).contiguous(), S.contiguous(), idx, nsel, Nk)
-        cnt = torch.zeros(B, Nk, device=P.device).scatter_add_(
-            1, idx.reshape(B, -1).long(), torch.ones(B, idx.shape[1] * k, device=P.device))
-        dP = T + cnt.unsqueeze(1) * (Ag + Bg * P)
-        return dP, dR, None, dgamma, dbeta, None, None, None
+        P, R, idx, gamma, beta, nsel, ysum, ysel, mean_rstd = ctx.saved_tensors
+        # dy_e = [e selected] S + A + Bc y_e per group (GroupNorm backward with a gradient that is non-zero on
+        # the selected edges only); the kernels turn that into dP, dR and the per-(b,c) sums behind dgamma / dbeta
+        dP, dR, sums = _native.edge_norm_backward(go.contiguous(), ysel, ysum, P, R, idx, nsel, gamma, beta, mean_rstd,
+                                                  ctx.slope)
+        dgb = sums.sum(dim=0)
+        return dP, dR, None, dgb[:, 1], dgb[:, 0], None, None, None
 
 
 class DGCNN_Grouper(nn.Module):
@@ -478,7 +452,7 @@ class DGCNN_Grouper(nn.Module):
         """One stage: max over the k neighbours of layer(get_graph_feature(...)) -> [B,C',Nq]."""
         conv, norm, act = layer[0], layer[1], layer[2]
         fused = (FUSED_EDGE_CONV and x_k.is_cuda and _native.backend_for_testing() is None and self.k <= 32
-                 and x_k.size(2) * 4 <= 64 * 1024 and conv.bias is None)
+                 and x_k.size(2) * 8 <= 64 * 1024 and conv.bias is None)
         if not fused:
             return layer(self.get_graph_feature(coor_q, x_q, coor_k, x_k)).max(dim=-1, keepdim=False)[0]
         with torch.no_grad():
