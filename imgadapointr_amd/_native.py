@@ -62,7 +62,8 @@ def _declare(lib):
         "ptops_layer_norm_max_dim": (c_int, []),
         "ptops_layer_norm_forward": (c_int, [P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P]),
         "ptops_layer_norm_backward_workspace_bytes": (c_size, [ctypes.c_longlong, c_int]),
-        "ptops_layer_norm_backward": (c_int, [P] * 5 + [ctypes.c_longlong, c_int, P, P, P, P]),
+        "ptops_add_layer_norm_forward": (c_int, [P, P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P, P]),
+        "ptops_layer_norm_backward": (c_int, [P] * 6 + [ctypes.c_longlong, c_int, P, P, P, P]),
         "ptops_attention_backward": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
     }
     for name, (res, args) in sig.items():
@@ -82,7 +83,8 @@ EXPORTS = (
     "ptops_attention_forward", "ptops_attention_backward", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
-    "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_layer_norm_backward_workspace_bytes",
+    "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_add_layer_norm_forward",
+    "ptops_layer_norm_backward_workspace_bytes",
     "ptops_layer_norm_backward",
 )
 
@@ -587,8 +589,28 @@ def layer_norm_forward(x, weight, bias, eps):
     return y, mean, rstd
 
 
-def layer_norm_backward(dy, x, mean, rstd, weight):
-    """-> (dx [rows, C], dgamma_dbeta [2*C])."""
+def add_layer_norm_forward(x, res, weight, bias, eps):
+    """x, res [rows, C] -> (s = x + res, y = LayerNorm(s), mean, rstd)."""
+    _check(x, "x", torch.float32, 2)
+    _check(res, "res", torch.float32, 2)
+    _check(weight, "weight", torch.float32, 1)
+    _check(bias, "bias", torch.float32, 1)
+    dev = _same_device(x, res, weight, bias)
+    rows, C = x.shape
+    if tuple(res.shape) != (rows, C) or weight.numel() != C or bias.numel() != C:
+        raise ValueError("add_layer_norm_forward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        s = torch.empty_like(x)
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        _call("ptops_add_layer_norm_forward", _ptr(x), _ptr(res), _ptr(weight), _ptr(bias), rows, C,
+              ctypes.c_float(float(eps)), _ptr(s), _ptr(y), _ptr(mean), _ptr(rstd), _stream(x))
+    return s, y, mean, rstd
+
+
+def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
+    """-> (dx [rows, C] (+ extra), dgamma_dbeta [2*C])."""
     _check(dy, "dy", torch.float32, 2)
     _check(x, "x", torch.float32, 2)
     _check(mean, "mean", torch.float32, 1)
@@ -598,13 +620,18 @@ def layer_norm_backward(dy, x, mean, rstd, weight):
     rows, C = x.shape
     if tuple(dy.shape) != (rows, C) or mean.numel() != rows or rstd.numel() != rows or weight.numel() != C:
         raise ValueError("layer_norm_backward: inconsistent shapes")
+    if extra is not None:
+        _check(extra, "extra", torch.float32, 2)
+        if tuple(extra.shape) != (rows, C) or extra.device != dev:
+            raise ValueError("layer_norm_backward: extra must match x")
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         ws = _scratch(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16))
         dx = torch.empty_like(x)
         dgb = torch.empty((2 * C,), dtype=torch.float32, device=dev)
-        _call("ptops_layer_norm_backward", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(weight), rows, C, _ptr(dx),
-              _ptr(dgb), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+        _call("ptops_layer_norm_backward", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(weight),
+              _ptr(extra) if extra is not None else None, rows, C, _ptr(dx), _ptr(dgb), _ptr(ws),
+              ctypes.c_void_p(stream.cuda_stream))
     return dx, dgb
 
 

@@ -29,8 +29,11 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // NV = number of 256-column slices a lane may hold (C <= 256 NV)
-template <int NV>
-__global__ __launch_bounds__(kWaves * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// ADD: the row is x + res and the sum is also written out (residual add fused into the following norm)
+template <int NV, bool ADD>
+__global__ __launch_bounds__(kWaves * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             float* __restrict__ sum_out,
+                                                             const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, long long rows, int C,
                                                              float eps, int rows_per_wave, float* __restrict__ y,
                                                              float* __restrict__ mean, float* __restrict__ rstd) {
@@ -54,6 +57,13 @@ __global__ __launch_bounds__(kWaves * 64) void ln_fwd_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       v[i] = in[i] ? ld4(xr + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD) {
+        if (in[i]) {
+          const float4 a = ld4(res + r * C + 4 * lane + 256 * i);
+          v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+          st4(sum_out + r * C + 4 * lane + 256 * i, v[i]);
+        }
+      }
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mu = wave_sum(s) * inv_c;
@@ -83,8 +93,10 @@ __global__ __launch_bounds__(kWaves * 64) void ln_fwd_kernel(const float* __rest
   }
 }
 
-template <int NV>
+// ADD: dx += extra (the gradient that reaches the normalised tensor through its other consumers)
+template <int NV, bool ADD>
 __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ extra,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, long long rows, int C,
                                                              int rows_per_wave, float* __restrict__ dx,
@@ -132,6 +144,10 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
         o.y = rs * (gy[i].y - m1 - xh[i].y * m2);
         o.z = rs * (gy[i].z - m1 - xh[i].z * m2);
         o.w = rs * (gy[i].w - m1 - xh[i].w * m2);
+        if constexpr (ADD) {
+          const float4 e = ld4(extra + r * C + 4 * lane + 256 * i);
+          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+        }
         st4(dxr + 4 * lane + 256 * i, o);
       }
     }
@@ -176,25 +192,40 @@ bool ln_args_ok(long long rows, int C) { return rows >= 0 && C >= 4 && C % 4 == 
 
 PTOPS_API int ptops_layer_norm_max_dim(void) { return 1024; }
 
-PTOPS_API int ptops_layer_norm_forward(const float* x, const float* gamma, const float* beta, long long rows, int C,
-                                       float eps, float* y, float* mean, float* rstd, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int ln_forward_impl(const float* x, const float* res, float* sum_out, const float* gamma, const float* beta,
+                           long long rows, int C, float eps, float* y, float* mean, float* rstd, hipStream_t stream) {
   PTOPS_REQUIRE(ln_args_ok(rows, C), "layer_norm_forward: need rows >= 0, C %% 4 == 0, 4 <= C <= 1024 (C=%d)", C);
   if (rows == 0) return PTOPS_OK;
   PTOPS_REQUIRE(x && gamma && beta && y && mean && rstd, "layer_norm_forward: null pointer");
-  PTOPS_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) == 0,
+  PTOPS_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)res | (uintptr_t)sum_out) & 15) == 0,
                 "layer_norm_forward: pointers must be 16-byte aligned");
   const int rpw = pick_rows_per_wave(rows, false);
   const long long blocks = (rows + (long long)rpw * kWaves - 1) / ((long long)rpw * kWaves);
   PTOPS_REQUIRE(blocks <= 0x7fffffffLL, "layer_norm_forward: too many rows");
   const dim3 grid((unsigned)blocks), block(kWaves * 64);
+#define PTOPS_LN_FWD(NV)                                                                                              \
+  if (res) hipLaunchKernelGGL((ln_fwd_kernel<NV, true>), grid, block, 0, stream, x, res, sum_out, gamma, beta, rows, C, eps, rpw, y, mean, rstd); \
+  else hipLaunchKernelGGL((ln_fwd_kernel<NV, false>), grid, block, 0, stream, x, res, sum_out, gamma, beta, rows, C, eps, rpw, y, mean, rstd)
   switch ((C + 255) / 256) {
-    case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, stream, x, gamma, beta, rows, C, eps, rpw, y, mean, rstd); break;
-    case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, gamma, beta, rows, C, eps, rpw, y, mean, rstd); break;
-    case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, gamma, beta, rows, C, eps, rpw, y, mean, rstd); break;
-    default: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, stream, x, gamma, beta, rows, C, eps, rpw, y, mean, rstd); break;
+    case 1: PTOPS_LN_FWD(1); break;
+    case 2: PTOPS_LN_FWD(2); break;
+    case 3: PTOPS_LN_FWD(3); break;
+    default: PTOPS_LN_FWD(4); break;
   }
+#undef PTOPS_LN_FWD
   return ptops::check_launch("ln_fwd_kernel");
+}
+
+PTOPS_API int ptops_layer_norm_forward(const float* x, const float* gamma, const float* beta, long long rows, int C,
+                                       float eps, float* y, float* mean, float* rstd, void* stream_) {
+  return ln_forward_impl(x, nullptr, nullptr, gamma, beta, rows, C, eps, y, mean, rstd, (hipStream_t)stream_);
+}
+
+PTOPS_API int ptops_add_layer_norm_forward(const float* x, const float* res, const float* gamma, const float* beta,
+                                           long long rows, int C, float eps, float* sum_out, float* y, float* mean,
+                                           float* rstd, void* stream_) {
+  PTOPS_REQUIRE(rows == 0 || (res && sum_out), "add_layer_norm_forward: null pointer");
+  return ln_forward_impl(x, res, sum_out, gamma, beta, rows, C, eps, y, mean, rstd, (hipStream_t)stream_);
 }
 
 static long long ln_bwd_blocks(long long rows) {
@@ -210,8 +241,8 @@ PTOPS_API size_t ptops_layer_norm_backward_workspace_bytes(long long rows, int C
 }
 
 PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const float* mean, const float* rstd,
-                                        const float* gamma, long long rows, int C, float* dx, float* dgamma_dbeta,
-                                        void* workspace, void* stream_) {
+                                        const float* gamma, const float* extra, long long rows, int C, float* dx,
+                                        float* dgamma_dbeta, void* workspace, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTOPS_REQUIRE(ln_args_ok(rows, C), "layer_norm_backward: need rows >= 0, C %% 4 == 0, 4 <= C <= 1024 (C=%d)", C);
   PTOPS_REQUIRE(dgamma_dbeta != nullptr, "layer_norm_backward: null output");
@@ -221,7 +252,7 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   }
   PTOPS_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "layer_norm_backward: null pointer");
   PTOPS_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)workspace |
-                  (uintptr_t)dgamma_dbeta) & 15) == 0,
+                  (uintptr_t)dgamma_dbeta | (uintptr_t)extra) & 15) == 0,
                 "layer_norm_backward: pointers must be 16-byte aligned");
   const int rpw = pick_rows_per_wave(rows, true);
   const long long blocks = ln_bwd_blocks(rows);
@@ -229,12 +260,16 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   float* partial = (float*)workspace;
   void* fold_ws = (char*)workspace + sizeof(float) * (size_t)blocks * 2 * C;
   const dim3 grid((unsigned)blocks), block(kWaves * 64);
+#define PTOPS_LN_BWD(NV)                                                                                                \
+  if (extra) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), grid, block, 0, stream, dy, x, extra, mean, rstd, gamma, rows, C, rpw, dx, partial); \
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), grid, block, 0, stream, dy, x, extra, mean, rstd, gamma, rows, C, rpw, dx, partial)
   switch ((C + 255) / 256) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, stream, dy, x, mean, rstd, gamma, rows, C, rpw, dx, partial); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, stream, dy, x, mean, rstd, gamma, rows, C, rpw, dx, partial); break;
-    case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, stream, dy, x, mean, rstd, gamma, rows, C, rpw, dx, partial); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, stream, dy, x, mean, rstd, gamma, rows, C, rpw, dx, partial); break;
+    case 1: PTOPS_LN_BWD(1); break;
+    case 2: PTOPS_LN_BWD(2); break;
+    case 3: PTOPS_LN_BWD(3); break;
+    default: PTOPS_LN_BWD(4); break;
   }
+#undef PTOPS_LN_BWD
   int rc = ptops::check_launch("ln_bwd_kernel");
   if (rc != PTOPS_OK) return rc;
   // dgamma_dbeta [2C] = column sums of the [blocks, 2C] partial rows

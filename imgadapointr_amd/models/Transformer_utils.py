@@ -124,6 +124,45 @@ class LayerNorm(nn.LayerNorm):
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (x + res, LayerNorm(x + res)); the backward folds the gradient arriving at s into the
+    LayerNorm backward pass, so neither the forward add nor the backward accumulate is a separate kernel."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        C = x.size(-1)
+        s, y, mean, rstd = _native.add_layer_norm_forward(x.contiguous().view(-1, C), res.contiguous().view(-1, C),
+                                                          weight, bias, eps)
+        ctx.save_for_backward(s, weight, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return s.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gs, gy):
+        s, weight, mean, rstd = ctx.saved_tensors
+        C = s.size(1)
+        if gy is None:
+            return gs, gs, None, None, None
+        extra = None if gs is None else gs.contiguous().view(-1, C)
+        dx, dgb = _native.layer_norm_backward(gy.contiguous().view(-1, C), s, mean, rstd, weight, extra)
+        dx = dx.view(gy.shape)
+        return dx, dx, dgb[:C], dgb[C:], None
+
+
+FUSED_ADD_LAYER_NORM = True
+
+
+def add_layer_norm(x, res, norm):
+    """-> (x + res, norm(x + res)) for an nn.LayerNorm-like `norm` (the residual add of a block fused into the
+    norm that follows it)."""
+    if (FUSED_ADD_LAYER_NORM and FAST_LAYER_NORM and isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1
+            and _native.backend_for_testing() is None and x.shape == res.shape and res.dtype == x.dtype
+            and _native.layer_norm_supported(x, norm.weight, norm.bias) and x.numel() >= 1 << 16):
+        return _AddLayerNormFn.apply(x, res, norm.weight, norm.bias, norm.eps)
+    s = x + res
+    return s, norm(s)
+
+
 # ------------------------------------------------------------------------------ functional
 def knn_idx(nsample, xyz, new_xyz):
     """int32 [B,S,nsample] neighbour indices, ordered by (distance, index).  No gradient."""

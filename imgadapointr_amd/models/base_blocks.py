@@ -19,6 +19,7 @@ import torch.nn as nn
 from .. import _native
 from ..pointnet2_ops import pointnet2_utils
 from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerNorm, LayerScale, Linear, Mlp,
+                                add_layer_norm,
                                 knn_idx, linear_on_broadcast_concat)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
@@ -113,7 +114,8 @@ class SelfAttnBlockApi(nn.Module):
             if len(feats) != self.block_length:
                 raise RuntimeError()
             f = self.merge_map(torch.cat(feats, dim=-1)) if len(feats) == 2 else feats[0]
-            x = x + self.drop_path1(self.ls1(f))
+            x, norm_x = add_layer_norm(x, self.drop_path1(self.ls1(f)), self.norm2)     # x = x + f; norm2(x)
+            return x + self.drop_path2(self.ls2(self.mlp(norm_x)))
         x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
         return x
 
@@ -220,14 +222,18 @@ class CrossAttnBlockApi(nn.Module):
             if len(feats) != self.self_attn_block_length:
                 raise RuntimeError()
             f = self.self_attn_merge_map(torch.cat(feats, dim=-1)) if len(feats) == 2 else feats[0]
-            q = q + self.drop_path1(self.ls1(f))
+            if self.cross_attn_block_length == 2 and self.cross_attn_combine_style == 'onebyone':
+                q = q + self.drop_path1(self.ls1(f))
+            else:                                                                       # q = q + f; norm_q(q)
+                q, norm_q = add_layer_norm(q, self.drop_path1(self.ls1(f)), self.norm_q)
 
         if self.cross_attn_block_length == 2 and self.cross_attn_combine_style == 'onebyone':
             q = q + self.drop_path4(self.ls4(self.cross_attn(self.norm_q(q), self.norm_v(v))))
             q = q + self.drop_path5(self.ls5(self.local_cross_attn(
                 q=self.norm_q_2(q), v=self.norm_v_2(v), q_pos=q_pos, v_pos=v_pos, idx=cross_attn_idx)))
         else:
-            norm_q = self.norm_q(q)
+            if self.self_attn_block_length == 2 and self.self_attn_combine_style == 'onebyone':
+                norm_q = self.norm_q(q)
             norm_v = self.norm_v(v)
             feats = []
             if self.cross_attn is not None:
@@ -237,7 +243,8 @@ class CrossAttnBlockApi(nn.Module):
             if len(feats) != self.cross_attn_block_length:
                 raise RuntimeError()
             f = self.cross_attn_merge_map(torch.cat(feats, dim=-1)) if len(feats) == 2 else feats[0]
-            q = q + self.drop_path4(self.ls4(f))
+            q, norm_q2 = add_layer_norm(q, self.drop_path4(self.ls4(f)), self.norm2)   # q = q + f; norm2(q)
+            return q + self.drop_path2(self.ls2(self.mlp(norm_q2)))
 
         q = q + self.drop_path2(self.ls2(self.mlp(self.norm2(q))))
         return q

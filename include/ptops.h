@@ -188,15 +188,21 @@ int ptops_attention_backward(const float* q, const float* k, const float* v, con
  * nn.LayerNorm over the last dimension (norm1 / norm2 / norm_q / norm_v of every transformer block,
  * models/base_blocks.py:88-118, 154-207) on row-major fp32 x [rows, C], C % 4 == 0, C <= 1024.
  * forward : y = (x - mean) * rstd * gamma + beta; mean, rstd [rows] are kept for the backward.
- * backward: dx [rows, C] and dgamma_dbeta [2*C] (dgamma then dbeta) in one pass over x and dy plus a
+ * add_layer_norm_forward: the same on x + res, which is also written to sum_out (the residual add
+ *           `x = x + f(...)` of a block fused into the norm that follows it).
+ * backward: dx [rows, C] (+ extra, if given: the gradient reaching the normalised tensor through its other
+ *           consumers) and dgamma_dbeta [2*C] (dgamma then dbeta) in one pass over x and dy plus a
  *           deterministic fold; workspace of ptops_layer_norm_backward_workspace_bytes(rows, C) bytes,
  *           16-byte aligned. */
 int ptops_layer_norm_max_dim(void);
 int ptops_layer_norm_forward(const float* x, const float* gamma, const float* beta, long long rows,
                              int C, float eps, float* y, float* mean, float* rstd, void* stream);
+int ptops_add_layer_norm_forward(const float* x, const float* res, const float* gamma,
+                                 const float* beta, long long rows, int C, float eps, float* sum_out,
+                                 float* y, float* mean, float* rstd, void* stream);
 size_t ptops_layer_norm_backward_workspace_bytes(long long rows, int C);
 int ptops_layer_norm_backward(const float* dy, const float* x, const float* mean, const float* rstd,
-                              const float* gamma, long long rows, int C, float* dx,
+                              const float* gamma, const float* extra, long long rows, int C, float* dx,
                               float* dgamma_dbeta, void* workspace, void* stream);
 
 /* ------------------------------------------------- fused edge-conv stage ----

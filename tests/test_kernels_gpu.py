@@ -427,6 +427,13 @@ def test_layer_norm_forward_and_backward(native, rows, C):
     go = torch.randn(rows, C, device="cuda") + 0.1
     y, mean, rstd = native.layer_norm_forward(x.detach(), w.detach(), b.detach(), 1e-5)
     dx, dgb = native.layer_norm_backward(go, x.detach(), mean, rstd, w.detach())
+    extra = torch.randn(rows, C, device="cuda")
+    dx_e, dgb_e = native.layer_norm_backward(go, x.detach(), mean, rstd, w.detach(), extra)
+    assert torch.equal(dgb_e, dgb) and (dx_e - (dx + extra)).abs().max().item() <= 1e-6 * max(1.0, dx.abs().max().item())
+    s_, y_, mean_, rstd_ = native.add_layer_norm_forward(x.detach(), extra, w.detach(), b.detach(), 1e-5)
+    assert torch.equal(s_, x.detach() + extra)
+    y2_, mean2_, rstd2_ = native.layer_norm_forward(s_, w.detach(), b.detach(), 1e-5)
+    assert torch.equal(y_, y2_) and torch.equal(mean_, mean2_) and torch.equal(rstd_, rstd2_)
     x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
     ref = torch.nn.functional.layer_norm(x64, (C,), w64, b64, 1e-5)
     gx, gw, gb = torch.autograd.grad(ref, (x64, w64, b64), go.double())
@@ -457,3 +464,32 @@ def test_layer_norm_module_matches_torch(native):
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
     assert sorted(ln.state_dict().keys()) == ["bias", "weight"]
+
+
+def test_fused_add_layer_norm_in_blocks(native):
+    """Decoder / encoder blocks with the residual add folded into the following LayerNorm vs the plain form."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    from imgadapointr_amd.models import base_blocks as BB
+    torch.manual_seed(11)
+    enc = BB.SelfAttnBlockApi(384, 6, mlp_ratio=2., qkv_bias=True, block_style='attn-graph', combine_style='concat', k=8).cuda()
+    dec = BB.CrossAttnBlockApi(384, 6, mlp_ratio=2., qkv_bias=True, self_attn_block_style='attn-graph',
+                               self_attn_combine_style='concat', cross_attn_block_style='attn-graph',
+                               cross_attn_combine_style='concat', k=8).cuda()
+    B, N, M = 8, 256, 128
+    x = torch.randn(B, N, 384, device="cuda", requires_grad=True)
+    v = torch.randn(B, M, 384, device="cuda", requires_grad=True)
+    pos, vpos = torch.rand(B, N, 3, device="cuda"), torch.rand(B, M, 3, device="cuda")
+    idx_s = TU.knn_point(8, pos, pos)
+    idx_c = TU.knn_point(8, vpos, pos)
+    res = {}
+    params = list(enc.parameters()) + list(dec.parameters())
+    for fused in (True, False):
+        TU.FUSED_ADD_LAYER_NORM = fused
+        h = enc(x, pos, idx=idx_s)
+        y = dec(h, v, pos, vpos, self_attn_idx=idx_s, cross_attn_idx=idx_c)
+        g = torch.autograd.grad(y.square().sum(), [x, v] + params)
+        res[fused] = [y.detach()] + [t.detach() for t in g]
+    TU.FUSED_ADD_LAYER_NORM = True
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() < 3e-5 * max(1.0, b.abs().max().item())
+
