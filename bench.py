@@ -104,6 +104,55 @@ class ChamferProbe:
         }
 
 
+class AttentionProbe:
+    """Events around every attention forward / backward launch of the library (the second family of MFMA-bound
+    hand-written kernels): executed fp32 MFMA FLOP/s against the 157.3 TFLOP/s peak."""
+
+    def __init__(self):
+        self.fwd, self.bwd = _native.attention_forward, _native.attention_backward
+        self.enabled = False
+        self.rec = {"forward": [], "backward": []}
+
+    @staticmethod
+    def _pairs(q, k, split_q, limit_k):
+        B, H, Nq, _ = q.shape
+        Nk = k.size(2)
+        return B * H * ((split_q * limit_k + (Nq - split_q) * Nk) if (split_q > 0 and limit_k < Nk) else Nq * Nk)
+
+    def forward(self, q, k, v, split_q, limit_k, scale):
+        if not self.enabled:
+            return self.fwd(q, k, v, split_q, limit_k, scale)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = self.fwd(q, k, v, split_q, limit_k, scale)
+        e.record()
+        self.rec["forward"].append((s, e, 4.0 * 64 * self._pairs(q, k, split_q, limit_k)))      # 2 GEMMs
+        return out
+
+    def backward(self, q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv):
+        if not self.enabled:
+            return self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv)
+        e.record()
+        self.rec["backward"].append((s, e, 14.0 * 64 * self._pairs(q, k, split_q, limit_k)))    # 7 GEMMs executed
+        return r
+
+    def summary(self, steps):
+        out = {"bound": "mfma", "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+               "note": "fp32 v_mfma_f32_32x32x2_f32; executed MFMA FLOPs (backward recomputes S and dP in both of its "
+                       "kernels: 7 GEMMs for 5 algorithmic ones); PMC MFMA-busy fractions in profiles/round1/attention_pmc.json"}
+        for kind, recs in self.rec.items():
+            if not recs:
+                continue
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[kind] = {"launches_per_step": len(recs) / steps, "ms_per_step": round(ms / steps, 3),
+                         "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4)}
+        return out
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """The same train step on the host cores through the CPU oracle, B=2 (BASELINE configs[0])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -199,6 +248,8 @@ def main():
 
     probe = ChamferProbe(N_GT, N_GT)
     _native.chamfer_forward = probe
+    aprobe = AttentionProbe()
+    _native.attention_forward, _native.attention_backward = aprobe.forward, aprobe.backward
 
     def barrier():
         if world > 1:
@@ -217,16 +268,18 @@ def main():
             note("first step done")
     barrier()
     note("timed region")
-    probe.enabled = True
+    probe.enabled = aprobe.enabled = True
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for i in range(args.steps):
         last = step(partial, gt)
+        aprobe.enabled = False          # 132 timing events per step cost ~0.9 ms: only the first timed step carries them
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
-    probe.enabled = False
+    probe.enabled = aprobe.enabled = False
     _native.chamfer_forward = probe.orig
+    _native.attention_forward, _native.attention_backward = aprobe.fwd, aprobe.bwd
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -247,6 +300,7 @@ def main():
                        "params": sum(p.numel() for p in model.parameters())},
             "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
             "roofline": probe.summary(),
+            "roofline_attention": aprobe.summary(1),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

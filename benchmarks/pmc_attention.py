@@ -1,0 +1,49 @@
+"""MFMA utilisation of the attention kernels from a rocprofv3 counter pass.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
+        --output-format csv -d /tmp/pmc -o attn -- python3 benchmarks/attention_bench.py
+    python3 benchmarks/pmc_attention.py /tmp/pmc/attn_counter_collection.csv /tmp/pmc/attn_kernel_trace.csv > profiles/roundN/attention_pmc.json
+
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles (summed over SIMDs) in which the matrix pipe is busy; GRBM_GUI_ACTIVE counts
+active cycles summed over the 8 XCDs.  utilisation = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)."""
+import collections
+import csv
+import json
+import sys
+
+
+def main():
+    counters, trace = sys.argv[1], sys.argv[2]
+    dur = collections.defaultdict(list)
+    with open(trace) as fh:
+        for r in csv.DictReader(fh):
+            n = r["Kernel_Name"]
+            if "attn_" in n and "anonymous" in n:
+                grid = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 0)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
+                wg = r.get("Workgroup_Size") or str(int(r.get("Workgroup_Size_X", 0)) * int(r.get("Workgroup_Size_Y", 1)) * int(r.get("Workgroup_Size_Z", 1)))
+                key = (n[n.index("attn_"):].split("(")[0], grid, wg)
+                dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(counters) as fh:
+        for r in csv.DictReader(fh):
+            n = r["Kernel_Name"]
+            if "attn_" in n and "anonymous" in n:
+                key = (n[n.index("attn_"):].split("(")[0], r["Grid_Size"], r["Workgroup_Size"])
+                vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = []
+    for key, cs in sorted(vals.items()):
+        avg = {c: sum(v) / len(v) for c, v in cs.items()}
+        d = dur.get(key, [])
+        rec = {"kernel": key[0], "grid_threads": int(key[1]), "workgroup": int(key[2]), "launches": len(next(iter(cs.values()))),
+               "avg_duration_us_under_pmc": round(sum(d) / len(d) / 1e3, 1) if d else None, "counters": avg}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+            simd_cycles = avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            rec["mfma_utilisation"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4)
+            rec["equivalent_fp32_mfma_tflops"] = round(rec["mfma_utilisation"] * 157.3, 1)
+        out.append(rec)
+    print(json.dumps({"note": __doc__.strip().splitlines()[-2] + " " + __doc__.strip().splitlines()[-1], "kernels": out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

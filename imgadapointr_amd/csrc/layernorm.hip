@@ -272,6 +272,7 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
 #undef PTOPS_LN_BWD
   int rc = ptops::check_launch("ln_bwd_kernel");
   if (rc != PTOPS_OK) return rc;
-  // dgamma_dbeta [2C] = column sums of the [blocks, 2C] partial rows
-  return ptops_colsum(partial, (int)blocks, 2 * C, dgamma_dbeta, fold_ws, stream_);
+  // dgamma_dbeta [2C] = column sums of the [blocks <= 1024, 2C] partial rows: one fold launch
+  (void)fold_ws;
+  return ptops_reduce::fold_rows(partial, (int)blocks, 2 * C, dgamma_dbeta, stream);
 }

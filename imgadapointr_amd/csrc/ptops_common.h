@@ -30,6 +30,11 @@ constexpr int kWave = 64;
 
 }  // namespace ptops
 
+// reduce.hip: out[n] = sum over the S rows of partial [S, N] in a fixed order, one launch (N % 4 == 0)
+namespace ptops_reduce {
+int fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream);
+}
+
 // chamfer_sweep.hip: exact pruned Chamfer search (sort by x + bounded sweep)
 namespace ptops_sweep {
 bool eligible(int B, int n, int m);

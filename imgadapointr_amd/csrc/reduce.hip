@@ -75,6 +75,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 }  // namespace
 
+int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream, partial, S, N, out);
+  return ptops::check_launch("colsum_final_kernel");
+}
+
 PTOPS_API size_t ptops_colsum_workspace_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
   return sizeof(float) * (size_t)ptops::ceil_div(M, kRowsPerBlock) * N;
