@@ -129,20 +129,21 @@ class AttentionProbe:
         self.rec["forward"].append((s, e, 4.0 * 64 * self._pairs(q, k, split_q, limit_k)))      # 2 GEMMs
         return out
 
-    def backward(self, q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv):
+    def backward(self, q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=True):
         if not self.enabled:
-            return self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv)
+            return self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=fused)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        r = self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv)
+        r = self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=fused)
         e.record()
-        self.rec["backward"].append((s, e, 14.0 * 64 * self._pairs(q, k, split_q, limit_k)))    # 7 GEMMs executed
+        gemms = 5.0 if fused else 7.0       # the dq + dk/dv pair evaluates S and dP twice
+        self.rec["backward"].append((s, e, 2.0 * gemms * 64 * self._pairs(q, k, split_q, limit_k)))
         return r
 
     def summary(self, steps):
         out = {"bound": "mfma", "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-               "note": "fp32 v_mfma_f32_32x32x2_f32; executed MFMA FLOPs (backward recomputes S and dP in both of its "
-                       "kernels: 7 GEMMs for 5 algorithmic ones); PMC MFMA-busy fractions in profiles/round1/attention_pmc.json"}
+               "note": "fp32 v_mfma_f32_32x32x2_f32; executed MFMA FLOPs (forward 2 GEMMs, single-pass backward 5); "
+                       "PMC MFMA-busy fractions in profiles/round1/attention_pmc.json"}
         for kind, recs in self.rec.items():
             if not recs:
                 continue

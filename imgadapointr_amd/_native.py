@@ -64,6 +64,8 @@ def _declare(lib):
         "ptops_layer_norm_backward_workspace_bytes": (c_size, [ctypes.c_longlong, c_int]),
         "ptops_add_layer_norm_forward": (c_int, [P, P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P, P]),
         "ptops_layer_norm_backward": (c_int, [P] * 6 + [ctypes.c_longlong, c_int, P, P, P, P]),
+        "ptops_attention_backward_fused_workspace_bytes": (c_size, [c_int] * 4),
+        "ptops_attention_backward_fused": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
         "ptops_attention_backward": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
     }
     for name, (res, args) in sig.items():
@@ -80,7 +82,8 @@ EXPORTS = (
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
-    "ptops_attention_forward", "ptops_attention_backward", "ptops_colsum_workspace_bytes", "ptops_colsum",
+    "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
+    "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_add_layer_norm_forward",
@@ -513,9 +516,10 @@ def attention_forward(q, k, v, split_q, limit_k, scale):
     return out, lse
 
 
-def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv):
+def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=True):
     """Gradients of attention_forward written into dq [B,H,Nq,64] / dk, dv [B,H,Nk,64] (strided views, e.g.
-    the slices of one packed allocation).  out/dout [B,Nq,H,64] contiguous, lse [B,H,Nq] from the forward."""
+    the slices of one packed allocation).  out/dout [B,Nq,H,64] contiguous, lse [B,H,Nq] from the forward.
+    fused=True: single-pass kernel (5 GEMMs); False: the dq + dk/dv pair (7 GEMMs)."""
     qs, ks, vs = _bhnd_strides(q, "q"), _bhnd_strides(k, "k"), _bhnd_strides(v, "v")
     dqs, dks, dvs = _bhnd_strides(dq, "dq"), _bhnd_strides(dk, "dk"), _bhnd_strides(dv, "dv")
     dev = _same_device(q, k, v, out, dout, lse, dq, dk, dv)
@@ -528,6 +532,13 @@ def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk,
     if not (out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attention_backward: out, dout and lse must be contiguous")
     with torch.cuda.device(dev):
+        if fused:
+            stream = torch.cuda.current_stream(dev)
+            ws = _scratch(dev, stream, max(load().ptops_attention_backward_fused_workspace_bytes(B, H, Nq, Nk), 16))
+            _call("ptops_attention_backward_fused", _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), B, H, Nq,
+                  Nk, qs, ks, vs, dqs, dks, dvs, int(split_q), int(limit_k), ctypes.c_float(float(scale)), _ptr(dq),
+                  _ptr(dk), _ptr(dv), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+            return
         delta = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
         _call("ptops_attention_backward", _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), B, H, Nq, Nk,
               qs, ks, vs, dqs, dks, dvs, int(split_q), int(limit_k), ctypes.c_float(float(scale)), _ptr(dq), _ptr(dk),

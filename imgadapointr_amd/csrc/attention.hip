@@ -500,6 +500,226 @@ __global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) 
   }
 }
 
+
+// ---- single-pass backward: dk, dv and dq from ONE evaluation of S and dP (5 GEMMs) ----------------------------
+// Eight waves per workgroup, each with a stationary 32-key tile (K^T, V^T in registers, dK^T / dV^T accumulators),
+// walk the query tiles together.  dQ[32 q x 64 dims] = dS[q x 256 keys] K[keys x dims] needs dS with the QUERY as the
+// row: every wave drops its dS tile (key on the lane) into a query-major LDS scratch, and after one barrier the
+// eight waves each compute one 16x16 block of the dQ tile over ALL keys of the workgroup with
+// v_mfma_f32_16x16x4_f32 (A = dS from the scratches, B = K from LDS copies of the key tiles): no reduction across
+// waves, no atomics, deterministic.  The workgroup writes dq directly when it holds all keys of the head
+// (Nk <= 256), else one partial per 256-key block that attn_dq_reduce_kernel folds in a fixed order.
+// D = rowsum(dO o O) is computed while the dO tile is staged.  LDS strides: scratch rows 34 and K rows 80 floats
+// make the 16x16x4 operand reads (lane = 16 rows x 4 k) bank-conflict-free.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+constexpr int kFW = 8;                       // waves per workgroup
+constexpr int kFusedKeys = kFW * 32;         // keys per workgroup
+constexpr int kTs = 34;                      // row stride of the dS scratch  [32 q][32 keys]
+constexpr int kKs = 80;                      // row stride of the K copies    [32 keys][64 dims]
+constexpr int kWaveLds = kTK * kTs + kTK * kKs;
+constexpr int kFusedLdsFloats = 2 * kTK * kLd + 2 * kTK + kFW * kWaveLds;
+
+struct AttnFusedArgs {
+  AttnBwdArgs a;
+  float* dq_partial;  // [n_kb, B*H, Nq, 64] when n_kb > 1
+  int n_kb;
+};
+
+__global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const AttnBwdArgs& a = fa.a;
+  float* sQ = lds;                         // [32][68]
+  float* sO = sQ + kTK * kLd;              // [32][68]  dO tile
+  float* sL = sO + kTK * kLd;              // lse[32], delta[32]
+  float* sW = sL + 2 * kTK;                // per wave: dS scratch [32][34], K copy [32][80]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sT = sW + wave * kWaveLds;
+  float* sK = sT + kTK * kTs;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int kb = blockIdx.x;
+  const int k0 = (kb * kFW + wave) * 32;
+  const bool active = k0 < a.Nk;
+  const float* qb = a.q + b * a.q_sb + head * a.q_sh;
+  const long long orow0 = ((long long)b * a.Nq * a.H + head) * kD;  // row stride H*64 (out and dout)
+  const float* dob = a.dout + orow0;
+  const float* ob = a.o + orow0;
+  const float* lb = a.lse + ((long long)b * a.H + head) * a.Nq;
+  const long long do_sn = (long long)a.H * kD;
+
+  const int blk_k0 = kb * kFusedKeys;
+  const int blk_qstart = (blk_k0 >= a.limit_k) ? a.split_q : 0;
+  const int my_qstart = active ? ((k0 >= a.limit_k) ? a.split_q : 0) : a.Nq;
+
+  float kf[32], vf[32];
+  if (active) {
+    const float* kp = a.k + b * a.k_sb + head * a.k_sh + (long long)(k0 + j) * a.k_sn + 32 * h;
+    const float* vp = a.v + b * a.v_sb + head * a.v_sh + (long long)(k0 + j) * a.v_sn + 32 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 4 * t);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp + 4 * t);
+      *reinterpret_cast<f32x4*>(&sK[j * kKs + 32 * h + 4 * t]) = k4;
+      kf[4 * t + 0] = k4.x * a.scale_log2e;
+      kf[4 * t + 1] = k4.y * a.scale_log2e;
+      kf[4 * t + 2] = k4.z * a.scale_log2e;
+      kf[4 * t + 3] = k4.w * a.scale_log2e;
+      vf[4 * t + 0] = v4.x;
+      vf[4 * t + 1] = v4.y;
+      vf[4 * t + 2] = v4.z;
+      vf[4 * t + 3] = v4.w;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      kf[t] = 0.0f;
+      vf[t] = 0.0f;
+    }
+  }
+
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+
+  // staging: thread e covers row e>>4, float4 column e&15 of the 32x64 tiles (512 threads = one float4 each)
+  const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+  f32x4 qreg, oreg;
+  float dpart = 0.0f, lreg = 0.0f;
+  auto fetch_tile = [&](int q0) {
+    qreg = *reinterpret_cast<const f32x4*>(qb + (long long)(q0 + sr) * a.q_sn + sc4);
+    oreg = *reinterpret_cast<const f32x4*>(dob + (long long)(q0 + sr) * do_sn + sc4);
+    const f32x4 o4 = *reinterpret_cast<const f32x4*>(ob + (long long)(q0 + sr) * do_sn + sc4);
+    dpart = fmaf(oreg.x, o4.x, fmaf(oreg.y, o4.y, fmaf(oreg.z, o4.z, oreg.w * o4.w)));
+    if (tid < kTK) lreg = lb[q0 + tid];
+  };
+  auto store_tile = [&]() {
+    *reinterpret_cast<f32x4*>(&sQ[sr * kLd + sc4]) = qreg;
+    *reinterpret_cast<f32x4*>(&sO[sr * kLd + sc4]) = oreg;
+    float d = dpart;  // D of row sr: sum over its 16 consecutive lanes
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 4);
+    d += __shfl_xor(d, 8);
+    if ((tid & 15) == 0) sL[kTK + sr] = d;
+    if (tid < kTK) sL[tid] = lreg;
+  };
+
+  // this wave's 16x16 block of the dQ tile
+  const int bq = (wave & 1) * 16, bd = (wave >> 1) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+
+  const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
+  if (t_begin < t_end) {
+    fetch_tile(t_begin * kTK);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) fetch_tile((t + 1) * kTK);
+    if (t * kTK >= my_qstart) {
+      f32x16 s = {0}, dp = {0};
+      const float* qr = &sQ[j * kLd + 32 * h];
+      const float* orow = &sO[j * kLd + 32 * h];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qr + 4 * g);
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(orow + 4 * g);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[4 * g + 0], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.x, vf[4 * g + 0], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[4 * g + 1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.y, vf[4 * g + 1], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[4 * g + 2], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.z, vf[4 * g + 2], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[4 * g + 3], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(o4.w, vf[4 * g + 3], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[8 * g + 4 * h]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sL[kTK + 8 * g + 4 * h]);
+        const float p0 = __builtin_amdgcn_exp2f(s[4 * g + 0] - l4.x);
+        const float p1 = __builtin_amdgcn_exp2f(s[4 * g + 1] - l4.y);
+        const float p2 = __builtin_amdgcn_exp2f(s[4 * g + 2] - l4.z);
+        const float p3 = __builtin_amdgcn_exp2f(s[4 * g + 3] - l4.w);
+        s[4 * g + 0] = p0;
+        s[4 * g + 1] = p1;
+        s[4 * g + 2] = p2;
+        s[4 * g + 3] = p3;
+        dp[4 * g + 0] = p0 * (dp[4 * g + 0] - d4.x);
+        dp[4 * g + 1] = p1 * (dp[4 * g + 1] - d4.y);
+        dp[4 * g + 2] = p2 * (dp[4 * g + 2] - d4.z);
+        dp[4 * g + 3] = p3 * (dp[4 * g + 3] - d4.w);
+      }
+      // dS (rows = queries (r&3)+8(r>>2)+4h, column = key j) -> scratch T[query][key]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * h) * kTs + j] = dp[r];
+      const float* oc = &sO[(4 * h) * kLd + j];
+      const float* qc = &sQ[(4 * h) * kLd + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        const float o0v = oc[row * kLd], o1v = oc[row * kLd + 32];
+        const float q0v = qc[row * kLd], q1v = qc[row * kLd + 32];
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o0v, s[r], dv0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0v, dp[r], dk0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o1v, s[r], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1v, dp[r], dk1, 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave's dS tile is in its scratch
+    {
+      // dQ block [bq..bq+16) x [bd..bd+16) over the keys of every wave that took part in this query tile
+      f32x4acc g = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < kFW; ++w) {
+        const int wk0 = (kb * kFW + w) * 32;
+        if (wk0 >= a.Nk || (wk0 >= a.limit_k && t * kTK < a.split_q)) continue;  // workgroup-uniform
+        const float* tw = sW + w * kWaveLds + (bq + li) * kTs + lk;   // A[i][k]: dS[q = bq+i][key 4u + k]
+        const float* kw = tw - ((bq + li) * kTs + lk) + kTK * kTs + lk * kKs + bd + li;  // B[k][n]: K[key 4u+k][bd+n]
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          g = __builtin_amdgcn_mfma_f32_16x16x4f32(tw[4 * u], kw[(4 * u) * kKs], g, 0, 0, 0);
+      }
+      // g[r]: query bq + 4*lk + r, dim bd + li
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = t * kTK + bq + 4 * lk + r;
+        if (fa.n_kb == 1)
+          a.dq[b * a.dq_sb + head * a.dq_sh + (long long)q * a.dq_sn + bd + li] = g[r] * a.scale;
+        else
+          fa.dq_partial[(((long long)kb * gridDim.y + bh) * a.Nq + q) * kD + bd + li] = g[r];
+      }
+    }
+    __syncthreads();  // all reads of sQ / sO / sL / the scratches done
+    if (t + 1 < t_end) store_tile();
+    __syncthreads();
+  }
+
+  if (active) {
+    store_dim_major(a.dk + b * a.dk_sb + head * a.dk_sh + (long long)(k0 + j) * a.dk_sn, dk0, dk1, h, a.scale);
+    store_dim_major(a.dv + b * a.dv_sb + head * a.dv_sh + (long long)(k0 + j) * a.dv_sn, dv0, dv1, h, 1.0f);
+  }
+}
+
+// dq = scale * sum over the key blocks that reach the query (fixed order)
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ partial, int n_kb, long long BH,
+                                                             int H, int Nq, int split_q, int limit_k, float scale,
+                                                             float* __restrict__ dq, long long dq_sb, long long dq_sh,
+                                                             long long dq_sn) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 of one (bh, q) row
+  const long long rows = BH * Nq;
+  if (e >= rows * 16) return;
+  const long long row = e >> 4;
+  const int c4 = (int)(e & 15) * 4;
+  const long long bh = row / Nq;
+  const int q = (int)(row - bh * Nq);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < n_kb; ++kb) {
+    if (q < split_q && kb * kFusedKeys >= limit_k) continue;  // that block never visited this query
+    const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (((long long)kb * BH + bh) * Nq + q) * kD + c4);
+    acc += v;
+  }
+  const long long b = bh / H, head = bh % H;
+  *reinterpret_cast<f32x4*>(dq + b * dq_sb + head * dq_sh + (long long)q * dq_sn + c4) = acc * scale;
+}
+
 }  // namespace
 
 PTOPS_API int ptops_attention_forward(const float* q, const float* k, const float* v, int B, int H, int Nq,
@@ -596,4 +816,61 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
     }
   }
   return ptops::check_launch("attn_bwd_dkv_kernel");
+}
+
+PTOPS_API size_t ptops_attention_backward_fused_workspace_bytes(int B, int H, int Nq, int Nk) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
+  const int n_kb = ptops::ceil_div(Nk, kFusedKeys);
+  return n_kb > 1 ? sizeof(float) * (size_t)n_kb * B * H * Nq * kD : 16;
+}
+
+PTOPS_API int ptops_attention_backward_fused(const float* q, const float* k, const float* v, const float* out,
+                                             const float* dout, const float* lse, int B, int H, int Nq, int Nk,
+                                             const long long* q_strides, const long long* k_strides,
+                                             const long long* v_strides, const long long* dq_strides,
+                                             const long long* dk_strides, const long long* dv_strides, int split_q,
+                                             int limit_k, float scale, float* dq, float* dk, float* dv,
+                                             void* workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && H >= 1 && Nq >= 0 && Nk >= 1, "attention_backward_fused: bad size");
+  if (B == 0 || Nq == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && workspace && q_strides && k_strides && v_strides &&
+                    dq_strides && dk_strides && dv_strides,
+                "attention_backward_fused: null pointer");
+  PTOPS_REQUIRE(Nq % 32 == 0 && Nk % 32 == 0, "attention_backward_fused: token counts must be multiples of 32 (Nq=%d Nk=%d)", Nq, Nk);
+  PTOPS_REQUIRE(split_q >= 0 && split_q <= Nq && split_q % 32 == 0 && limit_k >= 32 && limit_k <= Nk && limit_k % 32 == 0,
+                "attention_backward_fused: mask split (%d, %d) must be multiples of 32 within range", split_q, limit_k);
+  for (int i = 0; i < 3; ++i)
+    PTOPS_REQUIRE(q_strides[i] % 4 == 0 && k_strides[i] % 4 == 0 && v_strides[i] % 4 == 0 && dq_strides[i] % 4 == 0 &&
+                      dk_strides[i] % 4 == 0 && dv_strides[i] % 4 == 0,
+                  "attention_backward_fused: strides must keep rows 16-byte aligned");
+  PTOPS_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq |
+                  (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)workspace) & 15) == 0,
+                "attention_backward_fused: pointers must be 16-byte aligned");
+  PTOPS_REQUIRE((long long)B * H <= 65535, "attention_backward_fused: B*H exceeds the grid limit");
+  AttnFusedArgs fa;
+  AttnBwdArgs& a = fa.a;
+  a.q = q; a.k = k; a.v = v; a.o = out; a.dout = dout; a.lse = lse; a.delta = nullptr; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
+  a.dq_sb = dq_strides[0]; a.dq_sh = dq_strides[1]; a.dq_sn = dq_strides[2];
+  a.dk_sb = dk_strides[0]; a.dk_sh = dk_strides[1]; a.dk_sn = dk_strides[2];
+  a.dv_sb = dv_strides[0]; a.dv_sh = dv_strides[1]; a.dv_sn = dv_strides[2];
+  a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
+  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  fa.n_kb = ptops::ceil_div(Nk, kFusedKeys);
+  fa.dq_partial = (float*)workspace;
+  const size_t lds = sizeof(float) * (size_t)kFusedLdsFloats;
+  // 125 KB of dynamic LDS: above the 64 KB default cap (idempotent per-function setting)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(fa.n_kb, B * H), dim3(kFW * 64), lds, stream, fa);
+  int rc = ptops::check_launch("attn_bwd_fused_kernel");
+  if (rc != PTOPS_OK || fa.n_kb == 1) return rc;
+  const long long vec = (long long)B * H * Nq * 16;
+  hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)workspace, fa.n_kb, (long long)B * H, H, Nq, split_q, limit_k, scale, dq, a.dq_sb,
+                     a.dq_sh, a.dq_sn);
+  return ptops::check_launch("attn_dq_reduce_kernel");
 }

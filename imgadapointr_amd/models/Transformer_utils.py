@@ -28,8 +28,9 @@ USE_SDPA = True
 # PyTorch-ROCm's memory-efficient attention backward (aten::_efficient_attention_backward), which
 # consumes the same (out, logsumexp) pair.  Falls back to SDPA for shapes the kernel does not cover.
 USE_MFMA_ATTENTION = True
-# True: the attention backward runs on the library's two MFMA kernels; False: aten::_efficient_attention_backward
-USE_MFMA_ATTENTION_BWD = True
+# "fused": single-pass MFMA backward (5 GEMMs); "split": the dq + dk/dv kernel pair (7 GEMMs);
+# False: aten::_efficient_attention_backward
+USE_MFMA_ATTENTION_BWD = "fused"
 _LN2 = 0.6931471805599453
 _bias_cache = {}
 _zero_cache = {}
@@ -278,7 +279,8 @@ class _MFMAAttention(torch.autograd.Function):
             gq = torch.empty((B, Nq, H, 64), dtype=q.dtype, device=q.device).transpose(1, 2)
             gkv = torch.empty((B, Nk, 2, H, 64), dtype=q.dtype, device=q.device)
             gk, gv = gkv.permute(2, 0, 3, 1, 4).unbind(0)
-            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv)
+            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv,
+                                       fused=(USE_MFMA_ATTENTION_BWD == "fused"))
             return gq, gk, gv, None, None, None
         bias = None
         if split_q > 0 and limit_k < Nk:
@@ -312,7 +314,8 @@ class _MFMASelfAttention(torch.autograd.Function):
             g = torch.empty_like(qkv)
             q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
             gq, gk, gv = g.permute(2, 0, 3, 1, 4).unbind(0)
-            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv)
+            _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, split_q, limit_k, ctx.scale, gq, gk, gv,
+                                       fused=(USE_MFMA_ATTENTION_BWD == "fused"))
             return g, None, None, None
         q, k, v = qkv.unbind(2)                               # [B,N,h,d] views, the layout the op expects
         bias = None

@@ -184,6 +184,20 @@ int ptops_attention_backward(const float* q, const float* k, const float* v, con
                              int split_q, int limit_k, float scale, float* dq, float* dk,
                              float* dv, float* delta, void* stream);
 
+/* Single-pass variant: dk, dv and dq from one evaluation of S and dP (5 GEMMs instead of 7).  Eight
+ * stationary key tiles per workgroup; the dq tile is formed from all of them through LDS (no atomics) and,
+ * when Nk > 256, folded across 256-key blocks through `workspace`
+ * (ptops_attention_backward_fused_workspace_bytes bytes, 16-byte aligned) in a fixed order.  Same
+ * arguments and results as ptops_attention_backward (deterministic as well); no delta buffer. */
+size_t ptops_attention_backward_fused_workspace_bytes(int B, int H, int Nq, int Nk);
+int ptops_attention_backward_fused(const float* q, const float* k, const float* v, const float* out,
+                                   const float* dout, const float* lse, int B, int H, int Nq, int Nk,
+                                   const long long* q_strides, const long long* k_strides,
+                                   const long long* v_strides, const long long* dq_strides,
+                                   const long long* dk_strides, const long long* dv_strides,
+                                   int split_q, int limit_k, float scale, float* dq, float* dk,
+                                   float* dv, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------- LayerNorm --
  * nn.LayerNorm over the last dimension (norm1 / norm2 / norm_q / norm_v of every transformer block,
  * models/base_blocks.py:88-118, 154-207) on row-major fp32 x [rows, C], C % 4 == 0, C <= 1024.

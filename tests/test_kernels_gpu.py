@@ -273,9 +273,13 @@ def test_metrics_with_emd(native, ref):
 @pytest.mark.parametrize("Nq,Nk,split,limit", [(576, 576, 512, 512), (576, 256, 0, 256), (256, 256, 0, 256),
                                                 (512, 512, 0, 512), (96, 64, 32, 32), (32, 32, 0, 32),
                                                 (160, 224, 64, 96), (64, 608, 32, 576)])
-def test_attention_forward_and_backward(native, Nq, Nk, split, limit):
-    """fp32 MFMA attention vs an explicit float64 softmax(q k^T scale + mask) v, values and gradients."""
+@pytest.mark.parametrize("bwd", ["fused", "split"])
+def test_attention_forward_and_backward(native, Nq, Nk, split, limit, bwd, monkeypatch):
+    """fp32 MFMA attention vs an explicit float64 softmax(q k^T scale + mask) v, values and gradients
+    (both backward implementations: single-pass and the dq + dk/dv pair)."""
+    from imgadapointr_amd.models import Transformer_utils as TU
     from imgadapointr_amd.models.Transformer_utils import _MFMAAttention
+    monkeypatch.setattr(TU, "USE_MFMA_ATTENTION_BWD", bwd)
     torch.manual_seed(Nq + Nk)
     B, H, d = 3, 6, 64
     qkv = torch.randn(B, Nq, 3, H, d, device="cuda", requires_grad=True)     # strided q view, as in Attention
@@ -322,7 +326,7 @@ def test_packed_self_attention_and_linear_bias_grad(native):
     mask = torch.zeros(576, 576, device="cuda")
     mask[:512, 512:] = 1.
     outs = {}
-    for fast, native_bwd in ((True, True), (True, False), (False, False)):
+    for fast, native_bwd in ((True, "fused"), (True, "split"), (True, False), (False, False)):
         TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = fast
         TU.USE_MFMA_ATTENTION_BWD = native_bwd
         for p in attn.parameters():
@@ -330,8 +334,9 @@ def test_packed_self_attention_and_linear_bias_grad(native):
         y = attn(x, mask=mask, mask_split=(512, 512))
         g = torch.autograd.grad(y.square().sum(), [x] + list(attn.parameters()))
         outs[(fast, native_bwd)] = [y.detach()] + [t.detach() for t in g]
-    TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = TU.USE_MFMA_ATTENTION_BWD = True
-    for key in ((True, True), (True, False)):
+    TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = True
+    TU.USE_MFMA_ATTENTION_BWD = "fused"
+    for key in ((True, "fused"), (True, "split"), (True, False)):
         for a, b in zip(outs[key], outs[(False, False)]):
             scale = max(1.0, b.abs().max().item())
             assert (a - b).abs().max().item() < 2e-5 * scale, key
