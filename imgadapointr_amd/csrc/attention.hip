@@ -509,14 +509,16 @@ __global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) 
 // v_mfma_f32_16x16x4_f32 (A = dS from the scratches, B = K from LDS copies of the key tiles): no reduction across
 // waves, no atomics, deterministic.  The workgroup writes dq directly when it holds all keys of the head
 // (Nk <= 256), else one partial per 256-key block that attn_dq_reduce_kernel folds in a fixed order.
-// D = rowsum(dO o O) is computed while the dO tile is staged.  LDS strides: scratch rows 34 and K rows 80 floats
-// make the 16x16x4 operand reads (lane = 16 rows x 4 k) bank-conflict-free.
+// D = rowsum(dO o O) is computed while the dO tile is staged.  Both 16x16x4 operands are read as two ds_read_b128
+// per lane and key tile: MFMA step u of lane group k (= lane / 16) contracts key 8k + u, so a lane's eight values
+// are contiguous in the query-major dS scratch and in the dim-major K^T copy (row stride 36 floats: 16-byte
+// aligned rows, eight lanes of a group land on eight different bank quads).
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 constexpr int kFW = 8;                       // waves per workgroup
 constexpr int kFusedKeys = kFW * 32;         // keys per workgroup
-constexpr int kTs = 34;                      // row stride of the dS scratch  [32 q][32 keys]
-constexpr int kKs = 80;                      // row stride of the K copies    [32 keys][64 dims]
-constexpr int kWaveLds = kTK * kTs + kTK * kKs;
+constexpr int kTs = 36;                      // row stride of the dS scratch     [32 q][32 keys]
+constexpr int kKs = 36;                      // row stride of the K^T copies     [64 dims][32 keys]
+constexpr int kWaveLds = kTK * kTs + kD * kKs;
 constexpr int kFusedLdsFloats = 2 * kTK * kLd + 2 * kTK + kFW * kWaveLds;
 
 struct AttnFusedArgs {
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
   float* sQ = lds;                         // [32][68]
   float* sO = sQ + kTK * kLd;              // [32][68]  dO tile
   float* sL = sO + kTK * kLd;              // lse[32], delta[32]
-  float* sW = sL + 2 * kTK;                // per wave: dS scratch [32][34], K copy [32][80]
+  float* sW = sL + 2 * kTK;                // per wave: dS scratch [32 q][36], K^T copy [64 dims][36]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* sT = sW + wave * kWaveLds;
   float* sK = sT + kTK * kTs;
@@ -559,7 +561,10 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
     for (int t = 0; t < 8; ++t) {
       const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 4 * t);
       const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp + 4 * t);
-      *reinterpret_cast<f32x4*>(&sK[j * kKs + 32 * h + 4 * t]) = k4;
+      sK[(32 * h + 4 * t + 0) * kKs + j] = k4.x;   // K^T copy: [dim][key]
+      sK[(32 * h + 4 * t + 1) * kKs + j] = k4.y;
+      sK[(32 * h + 4 * t + 2) * kKs + j] = k4.z;
+      sK[(32 * h + 4 * t + 3) * kKs + j] = k4.w;
       kf[4 * t + 0] = k4.x * a.scale_log2e;
       kf[4 * t + 1] = k4.y * a.scale_log2e;
       kf[4 * t + 2] = k4.z * a.scale_log2e;
@@ -671,11 +676,19 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
       for (int w = 0; w < kFW; ++w) {
         const int wk0 = (kb * kFW + w) * 32;
         if (wk0 >= a.Nk || (wk0 >= a.limit_k && t * kTK < a.split_q)) continue;  // workgroup-uniform
-        const float* tw = sW + w * kWaveLds + (bq + li) * kTs + lk;   // A[i][k]: dS[q = bq+i][key 4u + k]
-        const float* kw = tw - ((bq + li) * kTs + lk) + kTK * kTs + lk * kKs + bd + li;  // B[k][n]: K[key 4u+k][bd+n]
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          g = __builtin_amdgcn_mfma_f32_16x16x4f32(tw[4 * u], kw[(4 * u) * kKs], g, 0, 0, 0);
+        // step u of lane group lk contracts key 8*lk + u:  A[i][.] = dS[q = bq+i][8lk+u],  B[.][n] = K[8lk+u][bd+n]
+        const float* tw = sW + w * kWaveLds + (bq + li) * kTs + 8 * lk;
+        const float* kw = sW + w * kWaveLds + kTK * kTs + (bd + li) * kKs + 8 * lk;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(tw), a1 = *reinterpret_cast<const f32x4*>(tw + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(kw), b1 = *reinterpret_cast<const f32x4*>(kw + 4);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, g, 0, 0, 0);
       }
       // g[r]: query bq + 4*lk + r, dim bd + li
 #pragma unroll
