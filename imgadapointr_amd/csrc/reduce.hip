@@ -55,28 +55,41 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ry == 0 && in) *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + col) = s;
 }
 
-// one workgroup per 64 columns; row-lane ry adds partials ry, ry+16, ... and the 16 lanes are folded in order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
-                                                           float* __restrict__ out) {
-  __shared__ float4 red[16][16];
+// one workgroup per 64 columns; row-lane ry adds partials ry, ry+RY, ... and the RY lanes are folded in order
+// (RY = 16 for the few slabs of a column sum, 64 when up to ~1000 partial rows have to be folded in one launch)
+template <int RY>
+__global__ __launch_bounds__(16 * RY) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
+                                                               float* __restrict__ out) {
+  __shared__ float4 red[RY][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int col = (blockIdx.x * 16 + cx) * 4;
   const bool in = col < N;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (in) {
-    for (int t = ry; t < S; t += 16) {
+    for (int t = ry; t < S; t += RY) {
       const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)t * N + col);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  const float4 s = fold16(red, acc, cx, ry);
-  if (ry == 0 && in) *reinterpret_cast<float4*>(out + col) = s;
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && in) {
+    float4 s = red[0][cx];
+    for (int t = 1; t < RY; ++t) {
+      const float4 v = red[t][cx];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + col) = s;
+  }
 }
 
 }  // namespace
 
 int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream, partial, S, N, out);
+  if (S > 64)
+    hipLaunchKernelGGL(colsum_final_kernel<64>, dim3(ptops::ceil_div(N, 64)), dim3(1024), 0, stream, partial, S, N, out);
+  else
+    hipLaunchKernelGGL(colsum_final_kernel<16>, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream, partial, S, N, out);
   return ptops::check_launch("colsum_final_kernel");
 }
 
@@ -100,7 +113,5 @@ PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* works
   PTOPS_REQUIRE(S <= 65535, "colsum: M=%d exceeds the grid limit", M);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ptops::ceil_div(N, 64), S), dim3(256), 0, stream, x, M, N,
                      (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream,
-                     (const float*)workspace, S, N, out);
-  return ptops::check_launch("colsum");
+  return ptops_reduce::fold_rows((const float*)workspace, S, N, out, stream);
 }
