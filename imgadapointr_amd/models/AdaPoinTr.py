@@ -15,11 +15,23 @@ import torch
 import torch.nn as nn
 
 from ..extensions.chamfer_dist import ChamferDistanceL1
+from .. import _native
 from ..pointnet2_ops import pointnet2_utils
 from .base_blocks import (DGCNN_Grouper, Fold, PointTransformerDecoderEntry, PointTransformerEncoderEntry,
                           SimpleRebuildFCLayer, trunc_normal_)
 from .build import MODELS
-from .Transformer_utils import Linear, index_points, knn_idx, linear_on_broadcast_concat
+from .Transformer_utils import Linear, _LinearFn, index_points, knn_idx, linear_on_broadcast_concat
+
+# True: AdaPoinTr.increase_dim (Conv1d 1x1 -> BatchNorm1d -> LeakyReLU -> Conv1d 1x1) runs token-major as two GEMMs
+TOKEN_MAJOR_INCREASE_DIM = True
+
+
+def _linear_tokens(x, weight, bias):
+    """F.linear on [rows, C]; on the GPU path through _LinearFn (streaming bias-gradient column sum)."""
+    if (x.is_cuda and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
+            and _native.backend_for_testing() is None and x.size(0) >= 2048):
+        return _LinearFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 class PCTransformer(nn.Module):
@@ -159,6 +171,22 @@ class AdaPoinTr(nn.Module):
     def build_trunk(self, config):
         return PCTransformer(config)
 
+    def _increase_dim(self, q):
+        """increase_dim on token-major data: the two 1x1 Conv1d are Linear layers over the channel dimension and
+        BatchNorm1d over [B,C,M] has the statistics of a 2-D batch norm over [B*M, C], so the [B,M,C] tokens go
+        through tuned GEMMs without the two transposes (and their copies) of `conv(q.transpose(1,2)).transpose(1,2)`
+        (AdaPoinTr.py:222-224 of the reference).  Same parameters, same state-dict keys."""
+        conv1, bn, act, conv2 = self.increase_dim
+        if not (TOKEN_MAJOR_INCREASE_DIM and isinstance(conv1, nn.Conv1d) and isinstance(bn, nn.BatchNorm1d)
+                and conv1.kernel_size == (1,) and conv2.kernel_size == (1,)):
+            return self.increase_dim(q.transpose(1, 2)).transpose(1, 2)
+        B, M, C = q.shape
+        h = _linear_tokens(q.reshape(B * M, C), conv1.weight.squeeze(-1), conv1.bias)
+        h = bn(h)                                                             # BatchNorm1d accepts [rows, C]
+        h = act(h)
+        h = _linear_tokens(h, conv2.weight.squeeze(-1), conv2.bias)
+        return h.view(B, M, -1)
+
     def coarse_loss_weight(self, epoch):
         return 1.0
 
@@ -190,7 +218,7 @@ class AdaPoinTr(nn.Module):
     def rebuild(self, q, coarse_point_cloud, denoise_length):
         B, M, C = q.shape
 
-        global_feature = self.increase_dim(q.transpose(1, 2)).transpose(1, 2)   # [B,M,1024]
+        global_feature = self._increase_dim(q)                                   # [B,M,1024]
         global_feature = torch.max(global_feature, dim=1)[0]
         # reduce_map(cat([global_feature broadcast (1024), q (C), coarse (3)])), AdaPoinTr.py:226-239
         rebuild_feature = linear_on_broadcast_concat(
