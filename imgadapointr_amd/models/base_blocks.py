@@ -63,6 +63,13 @@ def _init_linear_ln(m):
         nn.init.constant_(m.weight, 1.0)
 
 
+def _residual_out(x, branch, next_norm):
+    """x + branch, or (x + branch, next_norm(x + branch)) with the add folded into the following block's norm1."""
+    if next_norm is None:
+        return x + branch
+    return add_layer_norm(x, branch, next_norm)
+
+
 class SelfAttnBlockApi(nn.Module):
     """Pre-norm encoder block: [global attention ‖ local graph attention] -> MLP
     (base_blocks.py:14-109)."""
@@ -100,12 +107,14 @@ class SelfAttnBlockApi(nn.Module):
                 self.ls3 = LayerScale(dim, init_values=init_values) if init_values else nn.Identity()
                 self.drop_path3 = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward(self, x, pos, idx=None):
+    def forward(self, x, pos, idx=None, normed=None, next_norm=None):
+        """`normed`: norm1(x) if the caller already has it; `next_norm`: the following block's norm1 — then the
+        last residual add is folded into that norm and (x, next_norm(x)) is returned (see TransformerEncoder)."""
         if self.block_length == 2 and self.combine_style == 'onebyone':
-            x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
+            x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x) if normed is None else normed)))
             x = x + self.drop_path3(self.ls3(self.local_attn(self.norm3(x), pos, idx=idx)))
         else:
-            norm_x = self.norm1(x)
+            norm_x = self.norm1(x) if normed is None else normed
             feats = []
             if self.attn is not None:
                 feats.append(self.attn(norm_x))
@@ -115,9 +124,8 @@ class SelfAttnBlockApi(nn.Module):
                 raise RuntimeError()
             f = self.merge_map(torch.cat(feats, dim=-1)) if len(feats) == 2 else feats[0]
             x, norm_x = add_layer_norm(x, self.drop_path1(self.ls1(f)), self.norm2)     # x = x + f; norm2(x)
-            return x + self.drop_path2(self.ls2(self.mlp(norm_x)))
-        x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
-        return x
+            return _residual_out(x, self.drop_path2(self.ls2(self.mlp(norm_x))), next_norm)
+        return _residual_out(x, self.drop_path2(self.ls2(self.mlp(self.norm2(x)))), next_norm)
 
 
 class CrossAttnBlockApi(nn.Module):
@@ -199,8 +207,9 @@ class CrossAttnBlockApi(nn.Module):
         return mask
 
     def forward(self, q, v, q_pos, v_pos, self_attn_idx=None, cross_attn_idx=None, denoise_length=None,
-                denoise_mask=None):
-        """`denoise_mask`: the mask above, if the caller already built it (it is the same for every block)."""
+                denoise_mask=None, normed=None, next_norm=None):
+        """`denoise_mask`: the mask above, if the caller already built it (it is the same for every block).
+        `normed` / `next_norm`: as in SelfAttnBlockApi.forward (norm1 of this / of the following block)."""
         if denoise_length is None:
             mask = mask_split = None
         else:
@@ -209,11 +218,12 @@ class CrossAttnBlockApi(nn.Module):
             mask_split = (n - denoise_length, n - denoise_length)
 
         if self.self_attn_block_length == 2 and self.self_attn_combine_style == 'onebyone':
-            q = q + self.drop_path1(self.ls1(self.self_attn(self.norm1(q), mask=mask, mask_split=mask_split)))
+            q = q + self.drop_path1(self.ls1(self.self_attn(self.norm1(q) if normed is None else normed, mask=mask,
+                                                            mask_split=mask_split)))
             q = q + self.drop_path3(self.ls3(self.local_self_attn(
                 self.norm3(q), q_pos, idx=self_attn_idx, denoise_length=denoise_length)))
         else:
-            norm_q = self.norm1(q)
+            norm_q = self.norm1(q) if normed is None else normed
             feats = []
             if self.self_attn is not None:
                 feats.append(self.self_attn(norm_q, mask=mask, mask_split=mask_split))
@@ -244,10 +254,9 @@ class CrossAttnBlockApi(nn.Module):
                 raise RuntimeError()
             f = self.cross_attn_merge_map(torch.cat(feats, dim=-1)) if len(feats) == 2 else feats[0]
             q, norm_q2 = add_layer_norm(q, self.drop_path4(self.ls4(f)), self.norm2)   # q = q + f; norm2(q)
-            return q + self.drop_path2(self.ls2(self.mlp(norm_q2)))
+            return _residual_out(q, self.drop_path2(self.ls2(self.mlp(norm_q2))), next_norm)
 
-        q = q + self.drop_path2(self.ls2(self.mlp(self.norm2(q))))
-        return q
+        return _residual_out(q, self.drop_path2(self.ls2(self.mlp(self.norm2(q)))), next_norm)
 
 
 class TransformerEncoder(nn.Module):
@@ -269,8 +278,11 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, x, pos):
         idx = knn_idx(self.k, pos, pos)
-        for block in self.blocks:
-            x = block(x, pos, idx=idx)
+        normed = None
+        for i, block in enumerate(self.blocks):   # a block's last residual add is folded into the next block's norm1
+            nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+            out = block(x, pos, idx=idx, normed=normed, next_norm=nxt)
+            x, normed = out if nxt is not None else (out, None)
         return x
 
 
@@ -298,9 +310,12 @@ class TransformerDecoder(nn.Module):
         self_attn_idx = knn_idx(self.k, q_pos, q_pos) if denoise_length is None else None
         cross_attn_idx = knn_idx(self.k, v_pos, q_pos)
         mask = None if denoise_length is None else CrossAttnBlockApi.denoise_mask(q.size(1), denoise_length, q.device)
-        for block in self.blocks:
-            q = block(q, v, q_pos, v_pos, self_attn_idx=self_attn_idx, cross_attn_idx=cross_attn_idx,
-                      denoise_length=denoise_length, denoise_mask=mask)
+        normed = None
+        for i, block in enumerate(self.blocks):
+            nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+            out = block(q, v, q_pos, v_pos, self_attn_idx=self_attn_idx, cross_attn_idx=cross_attn_idx,
+                        denoise_length=denoise_length, denoise_mask=mask, normed=normed, next_norm=nxt)
+            q, normed = out if nxt is not None else (out, None)
         return q
 
 

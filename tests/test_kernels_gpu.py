@@ -498,3 +498,32 @@ def test_fused_add_layer_norm_in_blocks(native):
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() < 3e-5 * max(1.0, b.abs().max().item())
 
+
+
+def test_fused_add_layer_norm_across_blocks(native):
+    """TransformerEncoder / TransformerDecoder stacks: the last residual add of a block folded into the next block's
+    norm1 (and every in-block fusion) vs the plain form; outputs and all gradients."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    from imgadapointr_amd.models import base_blocks as BB
+    torch.manual_seed(12)
+    enc = BB.TransformerEncoder(embed_dim=384, depth=3, num_heads=6, mlp_ratio=2., qkv_bias=True,
+                                block_style_list=['attn-graph', 'attn', 'attn'], combine_style='concat', k=8).cuda()
+    dec = BB.TransformerDecoder(embed_dim=384, depth=3, num_heads=6, mlp_ratio=2., qkv_bias=True,
+                                self_attn_block_style_list=['attn-graph', 'attn', 'attn'], self_attn_combine_style='concat',
+                                cross_attn_block_style_list=['attn-graph', 'attn', 'attn'], cross_attn_combine_style='concat',
+                                k=8).cuda()
+    B, N, M = 8, 256, 128
+    x = torch.randn(B, M, 384, device="cuda", requires_grad=True)
+    q = torch.randn(B, N, 384, device="cuda", requires_grad=True)
+    pos, qpos = torch.rand(B, M, 3, device="cuda"), torch.rand(B, N, 3, device="cuda")
+    params = list(enc.parameters()) + list(dec.parameters())
+    res = {}
+    for fused in (True, False):
+        TU.FUSED_ADD_LAYER_NORM = fused
+        mem = enc(x, pos)
+        y = dec(q, mem, qpos, pos, denoise_length=64)
+        g = torch.autograd.grad(y.square().sum(), [x, q] + params)
+        res[fused] = [y.detach()] + [t.detach() for t in g]
+    TU.FUSED_ADD_LAYER_NORM = True
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() < 5e-5 * max(1.0, b.abs().max().item())
