@@ -58,6 +58,8 @@ __global__ __launch_bounds__(kTPB) void knn_kernel(const float* __restrict__ xyz
   __shared__ float4 cand[TILE];
   __shared__ float topd[kQPB][kMaxK];
   __shared__ int topi[kQPB][kMaxK];
+  __shared__ float survd[kWaves][64];  // per wave: candidates that passed the prefilter, in index order
+  __shared__ int survi[kWaves][64];
 
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * kQPB;
@@ -115,6 +117,76 @@ __global__ __launch_bounds__(kTPB) void knn_kernel(const float* __restrict__ xyz
       }
 
       int pos = 0;
+      if constexpr (P >= 16) {
+        // Prefilter (large tiles): the k-th smallest of the 64 per-lane minima is an upper bound tau on the k-th
+        // smallest candidate overall (they are 64 distinct candidates), so only candidates <= tau can be among the k
+        // best.  They are compacted in index order into a list of at most 64 (carried entries first: lower
+        // indices) and the extraction rounds then run on ONE value per lane instead of P + 1.
+        float t = fminf(lmin, dprev);
+        float tau = kInf;
+        for (int cnt = 0; cnt < k;) {
+          const float m = wave_min_f32(t);
+          if (!(m < kInf)) break;
+          const unsigned long long mask = __ballot(t == m);
+          cnt += __builtin_popcountll(mask);
+          t = (t == m) ? kInf : t;
+          tau = m;
+        }
+        int ns = 0;  // survivors so far (wave-uniform)
+        float sd = kInf;
+        int si = 0;
+        bool fits = true;
+        {
+          const bool keep = dprev <= tau;
+          const unsigned long long mask = __ballot(keep);
+          const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (keep) {
+            survd[wave][slot] = dprev;
+            survi[wave][slot] = iprev;
+          }
+          ns = __builtin_popcountll(mask);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const bool keep = d[p] <= tau;
+          const unsigned long long mask = __ballot(keep);
+          if (mask) {
+            const int slot = ns + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (keep && slot < 64) {
+              survd[wave][slot] = d[p];
+              survi[wave][slot] = c0 + lane + 64 * p;
+            }
+            ns += __builtin_popcountll(mask);
+          }
+        }
+        fits = ns <= 64;
+        if (fits) {
+          __builtin_amdgcn_wave_barrier();
+          if (lane < ns) {
+            sd = survd[wave][lane];
+            si = survi[wave][lane];
+          }
+          while (pos < k) {
+            const float m = wave_min_f32(sd);
+            if (!(m < kInf)) break;
+            const bool eq = sd == m;
+            const unsigned long long mask = __ballot(eq);
+            const int slot = pos + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (eq && slot < k) {
+              topd[qi][slot] = m;
+              topi[qi][slot] = si;
+            }
+            pos += __builtin_popcountll(mask);
+            sd = eq ? kInf : sd;
+          }
+          if (lane >= pos && lane < k) {
+            topd[qi][lane] = kInf;
+            topi[qi][lane] = 0;
+          }
+          continue;  // next query of this wave
+        }
+        // more than 64 candidates tie at or below tau (duplicated points): the general rounds below handle it
+      }
       while (pos < k) {
         float lm = dprev;
 #pragma unroll
