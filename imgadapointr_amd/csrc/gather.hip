@@ -272,6 +272,35 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_kernel(const float* __res
   }
 }
 
+// Same scatter through an LDS tile: a workgroup owns (b, 32 channels), accumulates every query's contribution
+// with ds_add_f32 into tile[channel][source point] (row stride N + 1: the 32 channels of a query land on 32
+// banks) and writes the tile out once — no global atomics, no memset.  Used when the tile fits (N <= 1024).
+constexpr int kGmCT = 32;
+
+__global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* __restrict__ grad_out,
+                                                                  const int32_t* __restrict__ arg, int N, int C,
+                                                                  int S, float* __restrict__ grad_p) {
+  extern __shared__ float gm_tile[];  // [kGmCT][N + 1]
+  const int b = blockIdx.y, c0 = blockIdx.x * kGmCT;
+  const int ld = N + 1;
+  for (int t = threadIdx.x; t < kGmCT * ld; t += kTPB) gm_tile[t] = 0.0f;
+  __syncthreads();
+  const int ct = threadIdx.x & (kGmCT - 1), sl = threadIdx.x / kGmCT;  // 32 channels x 8 query lanes
+  const int c = c0 + ct;
+  if (c < C) {
+    for (int s = sl; s < S; s += kTPB / kGmCT) {
+      const long long e = ((long long)b * S + s) * C + c;
+      atomicAdd(&gm_tile[ct * ld + arg[e]], grad_out[e]);
+    }
+  }
+  __syncthreads();
+  // write-out: lanes over channels (contiguous in grad_p), rows over source points
+  for (int t = threadIdx.x; t < kGmCT * N; t += kTPB) {
+    const int cc = t & (kGmCT - 1), n = t / kGmCT;
+    if (c0 + cc < C) grad_p[((long long)b * N + n) * C + c0 + cc] = gm_tile[cc * ld + n];
+  }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -415,8 +444,17 @@ PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* ar
   PTOPS_REQUIRE(B >= 0 && N >= 1 && C >= 1 && S >= 0, "gather_max_backward: bad size");
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_p, "gather_max_backward: null pointer");
-  (void)hipMemsetAsync(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);
   const long long total = (long long)B * S * C;
+  if (total > 0 && N <= 1024 && B <= 65535) {
+    PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
+    const size_t lds = sizeof(float) * (size_t)kGmCT * (N + 1);   // <= 131 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * kGmCT * 1025));
+    hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out,
+                       arg, N, C, S, grad_p);
+    return ptops::check_launch("gather_max_bwd_lds_kernel");
+  }
+  (void)hipMemsetAsync(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);
   if (total == 0) return ptops::check_launch("gather_max_backward(memset)");
   PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
   hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(grid_for(total)), dim3(kTPB), 0, stream, grad_out, arg, N,
