@@ -64,6 +64,9 @@ def _declare(lib):
         "ptops_layer_norm_backward_workspace_bytes": (c_size, [ctypes.c_longlong, c_int]),
         "ptops_add_layer_norm_forward": (c_int, [P, P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P, P]),
         "ptops_layer_norm_backward": (c_int, [P] * 6 + [ctypes.c_longlong, c_int, P, P, P, P]),
+        "ptops_batch_norm_rows_workspace_bytes": (c_size, [c_int, c_int]),
+        "ptops_batch_norm_rows_forward": (c_int, [P, P, P, c_int, c_int, ctypes.c_float, ctypes.c_float, P, P, P, P, P]),
+        "ptops_batch_norm_rows_backward": (c_int, [P] * 5 + [c_int, c_int, ctypes.c_float, P, P, P, P]),
         "ptops_attention_backward_fused_workspace_bytes": (c_size, [c_int] * 4),
         "ptops_attention_backward_fused": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
         "ptops_attention_backward": (c_int, [P] * 6 + [c_int] * 4 + [P] * 6 + [c_int, c_int, ctypes.c_float] + [P] * 5),
@@ -86,6 +89,7 @@ EXPORTS = (
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
+    "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
     "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_add_layer_norm_forward",
     "ptops_layer_norm_backward_workspace_bytes",
     "ptops_layer_norm_backward",
@@ -644,6 +648,40 @@ def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
               _ptr(extra) if extra is not None else None, rows, C, _ptr(dx), _ptr(dgb), _ptr(ws),
               ctypes.c_void_p(stream.cuda_stream))
     return dx, dgb
+
+
+def batch_norm_rows_forward(x, weight, bias, eps, slope):
+    """x [M,N] -> (y = LeakyReLU(batch-norm over rows), stats [2N] = {mean, rstd}, var [N] biased)."""
+    _check(x, "x", torch.float32, 2)
+    _check(weight, "weight", torch.float32, 1)
+    _check(bias, "bias", torch.float32, 1)
+    dev = _same_device(x, weight, bias)
+    M, N = x.shape
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        ws = _scratch(dev, stream, max(load().ptops_batch_norm_rows_workspace_bytes(M, N), 16))
+        y = torch.empty_like(x)
+        stats = torch.empty((2 * N,), dtype=torch.float32, device=dev)
+        var = torch.empty((N,), dtype=torch.float32, device=dev)
+        _call("ptops_batch_norm_rows_forward", _ptr(x), _ptr(weight), _ptr(bias), M, N, ctypes.c_float(float(eps)),
+              ctypes.c_float(float(slope)), _ptr(y), _ptr(stats), _ptr(var), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+    return y, stats, var
+
+
+def batch_norm_rows_backward(dy, x, stats, weight, bias, slope):
+    """-> (dx [M,N], dbeta_dgamma [2N])."""
+    _check(dy, "dy", torch.float32, 2)
+    _check(x, "x", torch.float32, 2)
+    dev = _same_device(dy, x, stats, weight, bias)
+    M, N = x.shape
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        ws = _scratch(dev, stream, max(load().ptops_batch_norm_rows_workspace_bytes(M, N), 16))
+        dx = torch.empty_like(x)
+        dbg = torch.empty((2 * N,), dtype=torch.float32, device=dev)
+        _call("ptops_batch_norm_rows_backward", _ptr(dy), _ptr(x), _ptr(stats), _ptr(weight), _ptr(bias), M, N,
+              ctypes.c_float(float(slope)), _ptr(dx), _ptr(dbg), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
+    return dx, dbg
 
 
 def edge_select(P, R, idx, take_max):

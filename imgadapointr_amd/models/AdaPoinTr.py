@@ -26,6 +26,31 @@ from .Transformer_utils import Linear, _LinearFn, index_points, knn_idx, linear_
 TOKEN_MAJOR_INCREASE_DIM = True
 
 
+class _BatchNormRowsLeakyReLU(torch.autograd.Function):
+    """LeakyReLU(BatchNorm1d(x)) in training mode for x [rows, C] on the library's column-moment kernels
+    (csrc/batchnorm.hip); updates the module's running statistics exactly as nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, slope):
+        y, stats, var = _native.batch_norm_rows_forward(x, weight, bias, bn.eps, slope)
+        M, C = x.shape
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - mom).add_(stats[:C], alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var, alpha=mom * M / max(M - 1, 1))      # unbiased, as torch
+        ctx.save_for_backward(x, stats, weight, bias)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, weight, bias = ctx.saved_tensors
+        C = x.size(1)
+        dx, dbg = _native.batch_norm_rows_backward(gy.contiguous(), x, stats, weight, bias, ctx.slope)
+        return dx, dbg[C:], dbg[:C], None, None
+
+
 def _linear_tokens(x, weight, bias):
     """F.linear on [rows, C]; on the GPU path through _LinearFn (streaming bias-gradient column sum)."""
     if (x.is_cuda and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
@@ -182,8 +207,11 @@ class AdaPoinTr(nn.Module):
             return self.increase_dim(q.transpose(1, 2)).transpose(1, 2)
         B, M, C = q.shape
         h = _linear_tokens(q.reshape(B * M, C), conv1.weight.squeeze(-1), conv1.bias)
-        h = bn(h)                                                             # BatchNorm1d accepts [rows, C]
-        h = act(h)
+        if (bn.training and h.is_cuda and h.dtype == torch.float32 and _native.backend_for_testing() is None
+                and bn.affine and bn.track_running_stats and isinstance(act, nn.LeakyReLU) and h.size(1) % 4 == 0):
+            h = _BatchNormRowsLeakyReLU.apply(h.contiguous(), bn.weight, bn.bias, bn, act.negative_slope)
+        else:
+            h = act(bn(h))                                                    # BatchNorm1d accepts [rows, C]
         h = _linear_tokens(h, conv2.weight.squeeze(-1), conv2.bias)
         return h.view(B, M, -1)
 

@@ -219,6 +219,21 @@ int ptops_layer_norm_backward(const float* dy, const float* x, const float* mean
                               const float* gamma, const float* extra, long long rows, int C, float* dx,
                               float* dgamma_dbeta, void* workspace, void* stream);
 
+/* ------------------------------------------- BatchNorm over rows + LeakyReLU --
+ * Training-mode nn.BatchNorm1d followed by LeakyReLU(slope) for token-major data: x [M, N] row-major
+ * (N % 4 == 0), statistics per COLUMN over the M rows (what BatchNorm1d computes over (B, L) of a
+ * [B, N, L] tensor) — AdaPoinTr.increase_dim, models/AdaPoinTr.py:222-224.  slope = 1 disables the
+ * activation.  forward: y, stats [2N] = {mean, rstd} (kept for the backward), var_out [N] = biased
+ * batch variance (the caller updates the running statistics).  backward: dx and dbeta_dgamma [2N] =
+ * {dbeta, dgamma}.  workspace: ptops_batch_norm_rows_workspace_bytes(M, N) bytes, 16-byte aligned. */
+size_t ptops_batch_norm_rows_workspace_bytes(int M, int N);
+int ptops_batch_norm_rows_forward(const float* x, const float* gamma, const float* beta, int M, int N,
+                                  float eps, float slope, float* y, float* stats, float* var_out,
+                                  void* workspace, void* stream);
+int ptops_batch_norm_rows_backward(const float* dy, const float* x, const float* stats,
+                                   const float* gamma, const float* beta, int M, int N, float slope,
+                                   float* dx, float* dbeta_dgamma, void* workspace, void* stream);
+
 /* ------------------------------------------------- fused edge-conv stage ----
  * One stage of DGCNN_Grouper (models/base_blocks.py:565-623): with P = W1.x_k [B,C,Nk] and
  * R = (W2-W1).x_q [B,C,Nq] (the 1x1 convolution split over its two input halves) the value on edge

@@ -527,3 +527,30 @@ def test_fused_add_layer_norm_across_blocks(native):
     TU.FUSED_ADD_LAYER_NORM = True
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() < 5e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,slope", [(18432, 1024, 0.2), (1000, 64, 0.2), (4099, 128, 1.0)])
+def test_batch_norm_rows_matches_torch(native, M, N, slope):
+    """Column-moment BatchNorm (+ LeakyReLU) kernels vs nn.BatchNorm1d in float64, incl. running statistics."""
+    from imgadapointr_amd.models.AdaPoinTr import _BatchNormRowsLeakyReLU
+    torch.manual_seed(M + N)
+    x = (torch.randn(M, N, device="cuda") * 1.7 + 0.4).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(N).cuda().train()
+    with torch.no_grad():
+        bn.weight.normal_(1.0, 0.3)
+        bn.bias.normal_(0.0, 0.3)
+    ref_bn = torch.nn.BatchNorm1d(N).cuda().double().train()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    go = torch.randn(M, N, device="cuda")
+    y = _BatchNormRowsLeakyReLU.apply(x, bn.weight, bn.bias, bn, slope)
+    gx, gw, gb = torch.autograd.grad(y, (x, bn.weight, bn.bias), go)
+    x64 = x.detach().double().requires_grad_(True)
+    r = torch.nn.functional.leaky_relu(ref_bn(x64), slope)
+    rx, rw, rb = torch.autograd.grad(r, (x64, ref_bn.weight, ref_bn.bias), go.double())
+    assert (y.double() - r).abs().max().item() < 2e-5
+    assert (gx.double() - rx).abs().max().item() < 2e-5 * max(1.0, rx.abs().max().item())
+    assert (gw.double() - rw).abs().max().item() < 1e-4 * max(1.0, rw.abs().max().item())
+    assert (gb.double() - rb).abs().max().item() < 1e-4 * max(1.0, rb.abs().max().item())
+    assert (bn.running_mean.double() - ref_bn.running_mean).abs().max().item() < 1e-6
+    assert (bn.running_var.double() - ref_bn.running_var).abs().max().item() < 1e-5
+    assert int(bn.num_batches_tracked) == 1
