@@ -94,3 +94,21 @@ def test_registry_contract():
     assert MODELS.get("AdaPoinTr") is not None
     with pytest.raises(KeyError):
         build_model_from_cfg(EasyDict(NAME="PoinTr"))  # unregistered, as in the reference
+
+
+def test_analytic_normals_eigenvector_matches_eigh():
+    """Closed-form smallest eigenvector of 3x3 covariances vs torch.linalg.eigh (planar, generic, degenerate)."""
+    from imgadapointr_amd.models.segmentation import normals as N
+    torch.manual_seed(0)
+    X = torch.randn(4000, 30, 3, dtype=torch.float64)
+    X[:2000, :, 2] *= 0.01                                    # surface-like neighbourhoods
+    d = X - X.mean(1, keepdim=True)
+    cov = (d.unsqueeze(3) * d.unsqueeze(2)).mean(1)
+    v = N.smallest_eigenvector_sym3(cov)
+    w, V = torch.linalg.eigh(cov)
+    assert ((v * V[..., 0]).sum(-1).abs() - 1).abs().max().item() < 1e-12
+    assert ((cov @ v.unsqueeze(-1)).squeeze(-1) - w[:, :1] * v).abs().max().item() < 1e-13
+    deg = torch.eye(3, dtype=torch.float64).expand(3, 3, 3).clone()
+    deg[1] *= 0
+    out = N.smallest_eigenvector_sym3(deg)                    # no defined normal: falls back to eigh, stays finite
+    assert torch.isfinite(out).all() and ((out.norm(dim=-1) - 1).abs() < 1e-12).all()
