@@ -514,12 +514,11 @@ __global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) 
 // are contiguous in the query-major dS scratch and in the dim-major K^T copy (row stride 36 floats: 16-byte
 // aligned rows, eight lanes of a group land on eight different bank quads).
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
-constexpr int kFW = 8;                       // waves per workgroup
-constexpr int kFusedKeys = kFW * 32;         // keys per workgroup
+// FW = waves per workgroup (8: 256 keys, one workgroup per CU; 4: 128 keys, two per CU)
 constexpr int kTs = 36;                      // row stride of the dS scratch     [32 q][32 keys]
 constexpr int kKs = 36;                      // row stride of the K^T copies     [64 dims][32 keys]
 constexpr int kWaveLds = kTK * kTs + kD * kKs;
-constexpr int kFusedLdsFloats = 2 * kTK * kLd + 2 * kTK + kFW * kWaveLds;
+constexpr int fused_lds_floats(int fw) { return 2 * kTK * kLd + 2 * kTK + fw * kWaveLds; }
 
 struct AttnFusedArgs {
   AttnBwdArgs a;
@@ -527,7 +526,9 @@ struct AttnFusedArgs {
   int n_kb;
 };
 
+template <int kFW>
 __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedArgs fa) {
+  constexpr int kFusedKeys = kFW * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const AttnBwdArgs& a = fa.a;
   float* sQ = lds;                         // [32][68]
@@ -584,31 +585,39 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
 
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
 
-  // staging: thread e covers row e>>4, float4 column e&15 of the 32x64 tiles (512 threads = one float4 each)
+  // staging: thread e covers row e>>4 (+ 16 kFW per pass), float4 column e&15 of the 32x64 tiles
+  constexpr int kPass = 512 / (kFW * 64);   // 1 (512 threads) or 2 (256 threads)
   const int sr = tid >> 4, sc4 = (tid & 15) * 4;
-  f32x4 qreg, oreg;
-  float dpart = 0.0f, lreg = 0.0f;
+  f32x4 qreg[kPass], oreg[kPass];
+  float dpart[kPass], lreg = 0.0f;
   auto fetch_tile = [&](int q0) {
-    qreg = *reinterpret_cast<const f32x4*>(qb + (long long)(q0 + sr) * a.q_sn + sc4);
-    oreg = *reinterpret_cast<const f32x4*>(dob + (long long)(q0 + sr) * do_sn + sc4);
-    const f32x4 o4 = *reinterpret_cast<const f32x4*>(ob + (long long)(q0 + sr) * do_sn + sc4);
-    dpart = fmaf(oreg.x, o4.x, fmaf(oreg.y, o4.y, fmaf(oreg.z, o4.z, oreg.w * o4.w)));
+#pragma unroll
+    for (int u = 0; u < kPass; ++u) {
+      const int row = sr + u * (kFW * 4);
+      qreg[u] = *reinterpret_cast<const f32x4*>(qb + (long long)(q0 + row) * a.q_sn + sc4);
+      oreg[u] = *reinterpret_cast<const f32x4*>(dob + (long long)(q0 + row) * do_sn + sc4);
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(ob + (long long)(q0 + row) * do_sn + sc4);
+      dpart[u] = fmaf(oreg[u].x, o4.x, fmaf(oreg[u].y, o4.y, fmaf(oreg[u].z, o4.z, oreg[u].w * o4.w)));
+    }
     if (tid < kTK) lreg = lb[q0 + tid];
   };
   auto store_tile = [&]() {
-    *reinterpret_cast<f32x4*>(&sQ[sr * kLd + sc4]) = qreg;
-    *reinterpret_cast<f32x4*>(&sO[sr * kLd + sc4]) = oreg;
-    float d = dpart;  // D of row sr: sum over its 16 consecutive lanes
-    d += __shfl_xor(d, 1);
-    d += __shfl_xor(d, 2);
-    d += __shfl_xor(d, 4);
-    d += __shfl_xor(d, 8);
-    if ((tid & 15) == 0) sL[kTK + sr] = d;
+#pragma unroll
+    for (int u = 0; u < kPass; ++u) {
+      const int row = sr + u * (kFW * 4);
+      *reinterpret_cast<f32x4*>(&sQ[row * kLd + sc4]) = qreg[u];
+      *reinterpret_cast<f32x4*>(&sO[row * kLd + sc4]) = oreg[u];
+      float d = dpart[u];  // D of the row: sum over its 16 consecutive lanes
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      d += __shfl_xor(d, 8);
+      if ((tid & 15) == 0) sL[kTK + row] = d;
+    }
     if (tid < kTK) sL[tid] = lreg;
   };
 
-  // this wave's 16x16 block of the dQ tile
-  const int bq = (wave & 1) * 16, bd = (wave >> 1) * 16;
+  // this wave's 16x16 block(s) of the dQ tile: blocks wave, wave + kFW, ... of the 8
   const int li = lane & 15, lk = lane >> 4;
 
   const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
@@ -670,8 +679,10 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
       }
     }
     __syncthreads();  // every wave's dS tile is in its scratch
-    {
+#pragma unroll
+    for (int blk = wave; blk < 8; blk += kFW) {
       // dQ block [bq..bq+16) x [bd..bd+16) over the keys of every wave that took part in this query tile
+      const int bq = (blk & 1) * 16, bd = (blk >> 1) * 16;
       f32x4acc g = {0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < kFW; ++w) {
         const int wk0 = (kb * kFW + w) * 32;
@@ -712,8 +723,9 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
 }
 
 // dq = scale * sum over the key blocks that reach the query (fixed order)
-__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ partial, int n_kb, long long BH,
-                                                             int H, int Nq, int split_q, int limit_k, float scale,
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ partial, int n_kb, int keys_per_block,
+                                                             long long BH, int H, int Nq, int split_q, int limit_k,
+                                                             float scale,
                                                              float* __restrict__ dq, long long dq_sb, long long dq_sh,
                                                              long long dq_sn) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // one float4 of one (bh, q) row
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __rest
   const int q = (int)(row - bh * Nq);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int kb = 0; kb < n_kb; ++kb) {
-    if (q < split_q && kb * kFusedKeys >= limit_k) continue;  // that block never visited this query
+    if (q < split_q && kb * keys_per_block >= limit_k) continue;  // that block never visited this query
     const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (((long long)kb * BH + bh) * Nq + q) * kD + c4);
     acc += v;
   }
@@ -831,9 +843,14 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
   return ptops::check_launch("attn_bwd_dkv_kernel");
 }
 
+// 8 waves (256 keys) per workgroup: one workgroup holds every key of a head up to 256 keys (no dq partials) and
+// the 576-key training shape needs 3 instead of 5 partials (465 vs 476 us at B=32, H=6); 4 waves (128 keys, two
+// workgroups per CU) only where they tile the keys exactly and balance the CUs better (512 keys: 323 vs 385 us).
+static int fused_waves(int Nk) { return (Nk > 256 && Nk % 256 == 0) ? 4 : 8; }
+
 PTOPS_API size_t ptops_attention_backward_fused_workspace_bytes(int B, int H, int Nq, int Nk) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
-  const int n_kb = ptops::ceil_div(Nk, kFusedKeys);
+  const int n_kb = ptops::ceil_div(Nk, fused_waves(Nk) * 32);
   return n_kb > 1 ? sizeof(float) * (size_t)n_kb * B * H * Nq * kD : 16;
 }
 
@@ -872,18 +889,25 @@ PTOPS_API int ptops_attention_backward_fused(const float* q, const float* k, con
   a.dv_sb = dv_strides[0]; a.dv_sh = dv_strides[1]; a.dv_sn = dv_strides[2];
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
-  fa.n_kb = ptops::ceil_div(Nk, kFusedKeys);
+  const int fw = fused_waves(Nk);
+  fa.n_kb = ptops::ceil_div(Nk, fw * 32);
   fa.dq_partial = (float*)workspace;
-  const size_t lds = sizeof(float) * (size_t)kFusedLdsFloats;
-  // 125 KB of dynamic LDS: above the 64 KB default cap (idempotent per-function setting)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(fa.n_kb, B * H), dim3(kFW * 64), lds, stream, fa);
+  const size_t lds = sizeof(float) * (size_t)fused_lds_floats(fw);
+  // up to 128 KB of dynamic LDS: above the 64 KB default cap (idempotent per-function setting)
+  if (fw == 8) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(fa.n_kb, B * H), dim3(512), lds, stream, fa);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, dim3(fa.n_kb, B * H), dim3(256), lds, stream, fa);
+  }
   int rc = ptops::check_launch("attn_bwd_fused_kernel");
   if (rc != PTOPS_OK || fa.n_kb == 1) return rc;
   const long long vec = (long long)B * H * Nq * 16;
   hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, stream,
-                     (const float*)workspace, fa.n_kb, (long long)B * H, H, Nq, split_q, limit_k, scale, dq, a.dq_sb,
+                     (const float*)workspace, fa.n_kb, fw * 32, (long long)B * H, H, Nq, split_q, limit_k, scale, dq, a.dq_sb,
                      a.dq_sh, a.dq_sn);
   return ptops::check_launch("attn_dq_reduce_kernel");
 }
