@@ -205,8 +205,11 @@ __global__ __launch_bounds__(256) void chamfer_unpack_kernel(const unsigned long
   }
 }
 
-// One lane per point of either cloud; mirrors chamfer.cu:173-201 (atomicAdd into zeroed
-// gradients: own point += g*(p - nn), nearest neighbour -= the same).
+// One lane per point of either cloud; chamfer.cu:173-201 adds, for every point p with nearest neighbour o and
+// incoming gradient g,  +2g(p - o) to p's gradient and -2g(p - o) to o's (atomicAdd into zeroed arrays).  Every
+// point receives exactly one "own" term, so that half is a plain store in a first pass (which also replaces the
+// memset) and only the neighbour half uses atomics in a second pass.
+template <bool NEIGHBOUR>
 __global__ __launch_bounds__(256) void chamfer_grad_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, const int32_t* __restrict__ idx1,
     const int32_t* __restrict__ idx2, const float* __restrict__ gd1, const float* __restrict__ gd2,
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const float v = g * (p[d] - o[d]);
-      atomicAdd(gp + d, v);
-      atomicAdd(go + d, -v);
+      if (NEIGHBOUR) atomicAdd(go + d, -v);
+      else gp[d] = v;
     }
   }
 }
@@ -413,14 +416,18 @@ PTOPS_API int ptops_chamfer_backward(const float* xyz1, const float* xyz2, const
   hipStream_t stream = (hipStream_t)stream_;
   PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_backward: negative size");
   if (B == 0) return PTOPS_OK;
-  if (n) (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, stream);
-  if (m) (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, stream);
-  if (n == 0 || m == 0) return ptops::check_launch("chamfer_backward(memset)");
+  if (n == 0 || m == 0) {
+    if (n) (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, stream);
+    if (m) (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, stream);
+    return ptops::check_launch("chamfer_backward(memset)");
+  }
   PTOPS_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_dist1 && grad_dist2 && grad_xyz1 && grad_xyz2,
                 "chamfer_backward: null pointer");
   const long long total = (long long)B * ((long long)n + m);
   const int g = (int)(ptops::ceil_div_ll(total, 256) < 4096 ? ptops::ceil_div_ll(total, 256) : 4096);
-  hipLaunchKernelGGL(chamfer_grad_kernel, dim3(g), dim3(256), 0, stream, xyz1, xyz2, idx1, idx2,
+  hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(g), dim3(256), 0, stream, xyz1, xyz2, idx1, idx2,
+                     grad_dist1, grad_dist2, B, n, m, grad_xyz1, grad_xyz2);
+  hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(g), dim3(256), 0, stream, xyz1, xyz2, idx1, idx2,
                      grad_dist1, grad_dist2, B, n, m, grad_xyz1, grad_xyz2);
   return ptops::check_launch("chamfer_grad_kernel");
 }
