@@ -625,7 +625,7 @@ def add_layer_norm_forward(x, res, weight, bias, eps):
 
 
 def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
-    """-> (dx [rows, C] (+ extra), dgamma_dbeta [2*C])."""
+    """-> (dx [rows, C] (+ extra), [3*C] = dgamma | dbeta | column sums of dx)."""
     _check(dy, "dy", torch.float32, 2)
     _check(x, "x", torch.float32, 2)
     _check(mean, "mean", torch.float32, 1)
@@ -643,7 +643,7 @@ def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
         stream = torch.cuda.current_stream(dev)
         ws = _scratch(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16))
         dx = torch.empty_like(x)
-        dgb = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+        dgb = torch.empty((3 * C,), dtype=torch.float32, device=dev)
         _call("ptops_layer_norm_backward", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(weight),
               _ptr(extra) if extra is not None else None, rows, C, _ptr(dx), _ptr(dgb), _ptr(ws),
               ctypes.c_void_p(stream.cuda_stream))

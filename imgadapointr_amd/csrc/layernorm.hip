@@ -100,12 +100,12 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, long long rows, int C,
                                                              int rows_per_wave, float* __restrict__ dx,
-                                                             float* __restrict__ partial /* [grid, 2, C] */) {
-  __shared__ float4 red[kWaves][2 * NV][64];
+                                                             float* __restrict__ partial /* [grid, 3, C] */) {
+  __shared__ float4 red[kWaves][3 * NV][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r0 = ((long long)blockIdx.x * kWaves + wave) * rows_per_wave;
   const long long r1 = min(rows, r0 + rows_per_wave);
-  float4 g[NV], ag[NV], ab[NV];
+  float4 g[NV], ag[NV], ab[NV], ax[NV];   // partial dgamma, dbeta and column sums of the dx this kernel writes
   bool in[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
     g[i] = in[i] ? ld4(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_c = 1.0f / (float)C;
   for (long long r = r0; r < r1; ++r) {
@@ -149,30 +150,33 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
           o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
         }
         st4(dxr + 4 * lane + 256 * i, o);
+        ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
       }
     }
   }
-  // fold the four waves' dgamma / dbeta partials in a fixed order, one partial row per workgroup
+  // fold the four waves' dgamma / dbeta / column-sum partials in a fixed order, one partial row per workgroup
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    red[wave][2 * i][lane] = ag[i];
-    red[wave][2 * i + 1][lane] = ab[i];
+    red[wave][3 * i][lane] = ag[i];
+    red[wave][3 * i + 1][lane] = ab[i];
+    red[wave][3 * i + 2][lane] = ax[i];
   }
   __syncthreads();
   if (wave == 0) {
-    float* pg = partial + (size_t)blockIdx.x * 2 * C;
+    float* pg = partial + (size_t)blockIdx.x * 3 * C;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (in[i]) {
-        float4 sg = red[0][2 * i][lane], sb = red[0][2 * i + 1][lane];
 #pragma unroll
-        for (int w = 1; w < kWaves; ++w) {
-          const float4 a = red[w][2 * i][lane], c = red[w][2 * i + 1][lane];
-          sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
-          sb.x += c.x; sb.y += c.y; sb.z += c.z; sb.w += c.w;
+        for (int q = 0; q < 3; ++q) {
+          float4 sg = red[0][3 * i + q][lane];
+#pragma unroll
+          for (int w = 1; w < kWaves; ++w) {
+            const float4 a = red[w][3 * i + q][lane];
+            sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
+          }
+          st4(pg + q * C + 4 * lane + 256 * i, sg);
         }
-        st4(pg + 4 * lane + 256 * i, sg);
-        st4(pg + C + 4 * lane + 256 * i, sb);
       }
     }
   }
@@ -236,8 +240,7 @@ static long long ln_bwd_blocks(long long rows) {
 PTOPS_API size_t ptops_layer_norm_backward_workspace_bytes(long long rows, int C) {
   if (!ln_args_ok(rows, C) || rows == 0) return 0;
   const long long blocks = ln_bwd_blocks(rows);
-  const size_t part = sizeof(float) * (size_t)blocks * 2 * C;
-  return part + ptops_colsum_workspace_bytes((int)blocks, 2 * C);
+  return sizeof(float) * (size_t)blocks * 3 * C;
 }
 
 PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const float* mean, const float* rstd,
@@ -247,7 +250,7 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   PTOPS_REQUIRE(ln_args_ok(rows, C), "layer_norm_backward: need rows >= 0, C %% 4 == 0, 4 <= C <= 1024 (C=%d)", C);
   PTOPS_REQUIRE(dgamma_dbeta != nullptr, "layer_norm_backward: null output");
   if (rows == 0) {
-    (void)hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * (size_t)C, stream);
+    (void)hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 3 * (size_t)C, stream);
     return ptops::check_launch("layer_norm_backward(memset)");
   }
   PTOPS_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "layer_norm_backward: null pointer");
@@ -258,7 +261,6 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   const long long blocks = ln_bwd_blocks(rows);
   PTOPS_REQUIRE(blocks <= 0x7fffffffLL, "layer_norm_backward: too many rows");
   float* partial = (float*)workspace;
-  void* fold_ws = (char*)workspace + sizeof(float) * (size_t)blocks * 2 * C;
   const dim3 grid((unsigned)blocks), block(kWaves * 64);
 #define PTOPS_LN_BWD(NV)                                                                                                \
   if (extra) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), grid, block, 0, stream, dy, x, extra, mean, rstd, gamma, rows, C, rpw, dx, partial); \
@@ -272,7 +274,6 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
 #undef PTOPS_LN_BWD
   int rc = ptops::check_launch("ln_bwd_kernel");
   if (rc != PTOPS_OK) return rc;
-  // dgamma_dbeta [2C] = column sums of the [blocks <= 1024, 2C] partial rows: one fold launch
-  (void)fold_ws;
-  return ptops_reduce::fold_rows(partial, (int)blocks, 2 * C, dgamma_dbeta, stream);
+  // dgamma | dbeta | colsum(dx)  [3C] = column sums of the [blocks <= 1024, 3C] partial rows: one fold launch
+  return ptops_reduce::fold_rows(partial, (int)blocks, 3 * C, dgamma_dbeta, stream);
 }

@@ -77,11 +77,29 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = g2.t() @ x.reshape(-1, x.size(-1))
         if ctx.needs_input_grad[2]:
-            gb = _native.colsum(g2.contiguous())
+            gb = _take_column_sums(grad)
+            if gb is None:
+                gb = _native.colsum(g2.contiguous())
         return gx, gw, gb
 
 
 FAST_BIAS_GRAD = True
+# Column sums a producer kernel already has for a gradient tensor (the LayerNorm backward sums the dx it writes):
+# keyed by (data_ptr, shape) of that tensor and consumed by the backward of the Linear that receives it as grad.
+_column_sums = {}
+
+
+def _offer_column_sums(t, sums):
+    _column_sums[(t.data_ptr(), tuple(t.shape))] = (t, sums)   # holding `t` keeps the address from being reused
+
+
+def _take_column_sums(t):
+    hit = _column_sums.pop((t.data_ptr(), tuple(t.shape)), None)
+    return None if hit is None else hit[1]     # the table keeps the producer's tensor alive: same address = same data
+
+
+def _clear_column_sums():
+    _column_sums.clear()
 
 
 class Linear(nn.Linear):
@@ -111,7 +129,7 @@ class _LayerNormFn(torch.autograd.Function):
         x2, weight, mean, rstd = ctx.saved_tensors
         C = x2.size(1)
         dx, dgb = _native.layer_norm_backward(gy.contiguous().view(-1, C), x2, mean, rstd, weight)
-        return dx.view(gy.shape), dgb[:C], dgb[C:], None
+        return dx.view(gy.shape), dgb[:C], dgb[C:2 * C], None
 
 
 class LayerNorm(nn.LayerNorm):
@@ -147,7 +165,11 @@ class _AddLayerNormFn(torch.autograd.Function):
         extra = None if gs is None else gs.contiguous().view(-1, C)
         dx, dgb = _native.layer_norm_backward(gy.contiguous().view(-1, C), s, mean, rstd, weight, extra)
         dx = dx.view(gy.shape)
-        return dx, dx, dgb[:C], dgb[C:], None
+        # `res` usually is the output of a Linear (attention projection, merge map, MLP fc2): its bias gradient is the
+        # column sum of this very dx, which the kernel has just accumulated
+        _clear_column_sums()
+        _offer_column_sums(dx, dgb[2 * C:])
+        return dx, dx, dgb[:C], dgb[C:2 * C], None
 
 
 FUSED_ADD_LAYER_NORM = True

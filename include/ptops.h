@@ -205,9 +205,10 @@ int ptops_attention_backward_fused(const float* q, const float* k, const float* 
  * add_layer_norm_forward: the same on x + res, which is also written to sum_out (the residual add
  *           `x = x + f(...)` of a block fused into the norm that follows it).
  * backward: dx [rows, C] (+ extra, if given: the gradient reaching the normalised tensor through its other
- *           consumers) and dgamma_dbeta [2*C] (dgamma then dbeta) in one pass over x and dy plus a
- *           deterministic fold; workspace of ptops_layer_norm_backward_workspace_bytes(rows, C) bytes,
- *           16-byte aligned. */
+ *           consumers) and dgamma_dbeta [3*C] = dgamma | dbeta | column sums of the dx written (the bias
+ *           gradient of a Linear whose output was the `res` of add_layer_norm_forward) in one pass over x
+ *           and dy plus a deterministic fold; workspace of
+ *           ptops_layer_norm_backward_workspace_bytes(rows, C) bytes, 16-byte aligned. */
 int ptops_layer_norm_max_dim(void);
 int ptops_layer_norm_forward(const float* x, const float* gamma, const float* beta, long long rows,
                              int C, float eps, float* y, float* mean, float* rstd, void* stream);
