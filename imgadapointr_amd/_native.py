@@ -64,6 +64,8 @@ def _declare(lib):
         "ptops_layer_norm_backward_workspace_bytes": (c_size, [ctypes.c_longlong, c_int]),
         "ptops_add_layer_norm_forward": (c_int, [P, P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P, P]),
         "ptops_layer_norm_backward": (c_int, [P] * 6 + [ctypes.c_longlong, c_int, P, P, P, P]),
+        "ptops_gelu_backward_colsum_workspace_bytes": (c_size, [c_int, c_int]),
+        "ptops_gelu_backward_colsum": (c_int, [P, P, c_int, c_int, P, P, P, P]),
         "ptops_batch_norm_rows_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_batch_norm_rows_forward": (c_int, [P, P, P, c_int, c_int, ctypes.c_float, ctypes.c_float, P, P, P, P, P]),
         "ptops_batch_norm_rows_backward": (c_int, [P] * 5 + [c_int, c_int, ctypes.c_float, P, P, P, P]),
@@ -90,6 +92,7 @@ EXPORTS = (
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
+    "ptops_gelu_backward_colsum_workspace_bytes", "ptops_gelu_backward_colsum",
     "ptops_layer_norm_max_dim", "ptops_layer_norm_forward", "ptops_add_layer_norm_forward",
     "ptops_layer_norm_backward_workspace_bytes",
     "ptops_layer_norm_backward",
@@ -648,6 +651,24 @@ def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
               _ptr(extra) if extra is not None else None, rows, C, _ptr(dx), _ptr(dgb), _ptr(ws),
               ctypes.c_void_p(stream.cuda_stream))
     return dx, dgb
+
+
+def gelu_backward_colsum(x, dy):
+    """x, dy [M,N] -> (dpre = dy * gelu'(x), column sums of dpre [N])."""
+    _check(x, "x", torch.float32, 2)
+    _check(dy, "dy", torch.float32, 2)
+    dev = _same_device(x, dy)
+    M, N = x.shape
+    if tuple(dy.shape) != (M, N):
+        raise ValueError("gelu_backward_colsum: shapes differ")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        ws = _scratch(dev, stream, max(load().ptops_gelu_backward_colsum_workspace_bytes(M, N), 16))
+        dpre = torch.empty_like(x)
+        cs = torch.empty((N,), dtype=torch.float32, device=dev)
+        _call("ptops_gelu_backward_colsum", _ptr(x), _ptr(dy), M, N, _ptr(dpre), _ptr(cs), _ptr(ws),
+              ctypes.c_void_p(stream.cuda_stream))
+    return dpre, cs
 
 
 def batch_norm_rows_forward(x, weight, bias, eps, slope):

@@ -235,6 +235,14 @@ int ptops_batch_norm_rows_backward(const float* dy, const float* x, const float*
                                    const float* gamma, const float* beta, int M, int N, float slope,
                                    float* dx, float* dbeta_dgamma, void* workspace, void* stream);
 
+/* ------------------------------------------- GELU backward + column sums ----
+ * dpre = dy * gelu'(x) (exact erf GELU, as nn.GELU()) for row-major x, dy [M, N] (N % 4 == 0), together with
+ * colsum [N] = sum over rows of dpre — the bias gradient of the Linear that feeds the activation (Mlp.fc1,
+ * models/Transformer_utils.py:58-75).  workspace: ptops_gelu_backward_colsum_workspace_bytes(M, N) bytes. */
+size_t ptops_gelu_backward_colsum_workspace_bytes(int M, int N);
+int ptops_gelu_backward_colsum(const float* x, const float* dy, int M, int N, float* dpre,
+                               float* colsum, void* workspace, void* stream);
+
 /* ------------------------------------------------- fused edge-conv stage ----
  * One stage of DGCNN_Grouper (models/base_blocks.py:565-623): with P = W1.x_k [B,C,Nk] and
  * R = (W2-W1).x_q [B,C,Nq] (the 1x1 convolution split over its two input halves) the value on edge

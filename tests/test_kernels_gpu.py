@@ -557,3 +557,27 @@ def test_batch_norm_rows_matches_torch(native, M, N, slope):
     assert (bn.running_mean.double() - ref_bn.running_mean).abs().max().item() < 1e-6
     assert (bn.running_var.double() - ref_bn.running_var).abs().max().item() < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_gelu_backward_with_column_sums(native):
+    """Fused GELU backward (+ fc1 bias gradient) vs plain torch in an Mlp: outputs and all gradients."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(21)
+    mlp = TU.Mlp(384, 768).cuda()
+    x = torch.randn(32, 576, 384, device="cuda", requires_grad=True)
+    res = {}
+    for fused in (True, False):
+        TU.FUSED_GELU_BACKWARD = fused
+        y = mlp(x)
+        g = torch.autograd.grad(y.square().sum(), [x] + list(mlp.parameters()))
+        res[fused] = [y.detach()] + [t.detach() for t in g]
+    TU.FUSED_GELU_BACKWARD = True
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+    xx = torch.randn(3000, 96, device="cuda") * 3
+    gg = torch.randn(3000, 96, device="cuda")
+    dpre, cs = native.gelu_backward_colsum(xx, gg)
+    x64 = xx.double().requires_grad_(True)
+    (want,) = torch.autograd.grad(torch.nn.functional.gelu(x64), x64, gg.double())
+    assert (dpre.double() - want).abs().max().item() < 2e-6
+    assert (cs.double() - want.sum(0)).abs().max().item() < 1e-3
