@@ -20,7 +20,7 @@ from ..pointnet2_ops import pointnet2_utils
 from .base_blocks import (DGCNN_Grouper, Fold, PointTransformerDecoderEntry, PointTransformerEncoderEntry,
                           SimpleRebuildFCLayer, trunc_normal_)
 from .build import MODELS
-from .Transformer_utils import Linear, _LinearFn, index_points, knn_idx, linear_on_broadcast_concat
+from .Transformer_utils import GELU, Linear, _LinearFn, index_points, knn_idx, linear_on_broadcast_concat
 
 # True: AdaPoinTr.increase_dim (Conv1d 1x1 -> BatchNorm1d -> LeakyReLU -> Conv1d 1x1) runs token-major as two GEMMs
 TOKEN_MAJOR_INCREASE_DIM = True
@@ -75,17 +75,17 @@ class PCTransformer(nn.Module):
         self.denoise_num = 64
 
         self.grouper = DGCNN_Grouper(k=16)
-        self.pos_embed = nn.Sequential(Linear(in_chans, 128), nn.GELU(),
+        self.pos_embed = nn.Sequential(Linear(in_chans, 128), GELU(),
                                        Linear(128, encoder_config.embed_dim))
-        self.input_proj = nn.Sequential(Linear(self.grouper.num_features, 512), nn.GELU(),
+        self.input_proj = nn.Sequential(Linear(self.grouper.num_features, 512), GELU(),
                                         Linear(512, encoder_config.embed_dim))
         self.encoder = PointTransformerEncoderEntry(encoder_config)
-        self.increase_dim = nn.Sequential(Linear(encoder_config.embed_dim, 1024), nn.GELU(),
+        self.increase_dim = nn.Sequential(Linear(encoder_config.embed_dim, 1024), GELU(),
                                           Linear(1024, global_feature_dim))
         self.coarse_pred = nn.Sequential(nn.Linear(global_feature_dim, 1024), nn.GELU(),
                                          nn.Linear(1024, 3 * query_num))
-        self.mlp_query = nn.Sequential(nn.Linear(global_feature_dim + 3, 1024), nn.GELU(),
-                                       Linear(1024, 1024), nn.GELU(),
+        self.mlp_query = nn.Sequential(nn.Linear(global_feature_dim + 3, 1024), GELU(),
+                                       Linear(1024, 1024), GELU(),
                                        Linear(1024, decoder_config.embed_dim))
         if decoder_config.embed_dim == encoder_config.embed_dim:
             self.mem_link = nn.Identity()

@@ -283,7 +283,16 @@ def gelu(x, act):
             and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled() and x.size(-1) % 4 == 0
             and x.numel() // x.size(-1) >= 2048 and _native.backend_for_testing() is None):
         return _GeluFn.apply(x)
+    if isinstance(act, nn.GELU):
+        return F.gelu(x, approximate=getattr(act, "approximate", "none"))
     return act(x)
+
+
+class GELU(nn.GELU):
+    """nn.GELU() (no parameters, same state dict) that takes the fused backward when its input is large enough."""
+
+    def forward(self, x):
+        return gelu(x, self)
 
 
 class Mlp(nn.Module):
