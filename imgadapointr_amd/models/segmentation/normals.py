@@ -43,7 +43,8 @@ def smallest_eigenvector_sym3(A):
 
     Eigenvalues from the trigonometric solution of the characteristic cubic (Smith 1961); the eigenvector is the
     largest of the three cross products of rows of A - lambda I (each is orthogonal to the row space).  Matrices
-    whose two smallest eigenvalues coincide to rounding (no defined normal) fall back to the generic solver."""
+    whose two smallest eigenvalues coincide to rounding have no defined normal: they get a unit vector of that
+    eigen-plane (see below)."""
     if not ANALYTIC_EIGEN:
         return torch.linalg.eigh(A)[1][..., 0]
     a11, a22, a33 = A[..., 0, 0], A[..., 1, 1], A[..., 2, 2]
@@ -58,19 +59,34 @@ def smallest_eigenvector_sym3(A):
     lam_max = q + 2.0 * p * torch.cos(phi)
     lam_min = q + 2.0 * p * torch.cos(phi + 2.0943951023931953)          # + 2 pi / 3
     lam_mid = 3.0 * q - lam_max - lam_min
-    r0 = torch.stack([a11 - lam_min, a12, a13], dim=-1)
-    r1 = torch.stack([a12, a22 - lam_min, a23], dim=-1)
-    r2 = torch.stack([a13, a23, a33 - lam_min], dim=-1)
-    cands = torch.stack([torch.linalg.cross(r0, r1), torch.linalg.cross(r0, r2), torch.linalg.cross(r1, r2)], dim=-2)
-    norms = cands.norm(dim=-1)
-    best = norms.argmax(dim=-1, keepdim=True)
-    vec = cands.gather(-2, best.unsqueeze(-1).expand(*best.shape, 3)).squeeze(-2)
-    nb = norms.gather(-1, best)
+    def null_vector(lam):
+        """Largest cross product of two rows of A - lam I (orthogonal to its row space) and its norm."""
+        r0 = torch.stack([a11 - lam, a12, a13], dim=-1)
+        r1 = torch.stack([a12, a22 - lam, a23], dim=-1)
+        r2 = torch.stack([a13, a23, a33 - lam], dim=-1)
+        cands = torch.stack([torch.linalg.cross(r0, r1), torch.linalg.cross(r0, r2), torch.linalg.cross(r1, r2)], dim=-2)
+        norms = cands.norm(dim=-1)
+        best = norms.argmax(dim=-1, keepdim=True)
+        vec = cands.gather(-2, best.unsqueeze(-1).expand(*best.shape, 3)).squeeze(-2)
+        return vec, norms.gather(-1, best)
+
+    vec, nb = null_vector(lam_min)
     vec = vec / nb.clamp_min(1e-300)
-    # (near-)repeated smallest eigenvalue: the cross products vanish and the direction is not determined by A
+    # (near-)repeated smallest eigenvalue: the cross products vanish and A does not determine the direction.  Any unit
+    # vector orthogonal to the eigenvector of the largest eigenvalue is then an eigenvector of the repeated pair; a
+    # fully isotropic matrix gets e_x.  (No data-dependent branch: the forward stays capturable in a HIP graph.)
     scale = lam_max.abs().clamp_min(1e-300)
     bad = ((lam_mid - lam_min) <= 1e-9 * scale) | (nb.squeeze(-1) <= 1e-12 * scale * scale)
     bad = bad | ~torch.isfinite(vec).all(dim=-1)
-    if bool(bad.any()):
-        vec = torch.where(bad.unsqueeze(-1), torch.linalg.eigh(A)[1][..., 0], vec)
-    return vec
+    umax, nmax = null_vector(lam_max)
+    umax = umax / nmax.clamp_min(1e-300)
+    ex = torch.zeros_like(umax)
+    ex[..., 0] = 1.0
+    ey = torch.zeros_like(umax)
+    ey[..., 1] = 1.0
+    axis = torch.where((umax[..., :1].abs() < 0.9), ex, ey)
+    alt = torch.linalg.cross(umax, axis)
+    alt_n = alt.norm(dim=-1, keepdim=True)
+    iso = ((lam_max - lam_min) <= 1e-9 * scale).unsqueeze(-1) | ~torch.isfinite(alt).all(dim=-1, keepdim=True) | (alt_n <= 1e-6)
+    alt = torch.where(iso, ex, alt / alt_n.clamp_min(1e-300))
+    return torch.where(bad.unsqueeze(-1), alt, vec)

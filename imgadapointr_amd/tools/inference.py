@@ -41,7 +41,7 @@ def inference_single(model, pc_path, args, config, root=None):
                          {'callback': 'ToTensor', 'objects': ['input']}])
     x = transform({'input': pc})['input'].unsqueeze(0).to(args.device.lower())
     with torch.no_grad():
-        dense = model(x)[-1].squeeze(0).cpu().numpy()
+        dense = model(x)[-1].squeeze(0).cpu().numpy()     # `model` may be a GraphedForward (main): one HIP graph replay
     if shapenet:
         dense = dense * m + centroid
     target = os.path.join(args.out_pc_root, os.path.splitext(os.path.basename(pc_path))[0])
@@ -56,6 +56,9 @@ def main(argv=None):
     model = builder.model_builder(config.model)
     builder.load_model(model, args.model_checkpoint)
     model.to(args.device.lower()).eval()
+    if args.device.lower().startswith('cuda'):
+        from ..utils.graph_runner import GraphedForward
+        model = GraphedForward(model)                     # every cloud is up-sampled to 2048 points: one graph serves all
     if args.pc_root != '':
         for pc_file in sorted(os.listdir(args.pc_root)):
             inference_single(model, pc_file, args, config, root=args.pc_root)

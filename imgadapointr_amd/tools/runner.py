@@ -24,6 +24,7 @@ from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from ..utils import dist_utils
 from ..utils.AverageMeter import AverageMeter
 from ..utils.flat_ddp import FlatDDP
+from ..utils.graph_runner import GraphedForward
 from ..utils.logger import get_logger, print_log
 from ..utils.metrics import Metrics
 from . import builder
@@ -210,11 +211,13 @@ def validate(base_model, test_dataloader, epoch, ChamferDisL1, ChamferDisL2, val
     n_samples = len(test_dataloader)
     dataset_name = config.dataset.val._base_.NAME
     loss_L1, loss_L2 = [], []
+    # bs = 1 validation is launch-bound: replay the forward as one HIP graph per input shape (utils/graph_runner.py)
+    forward = GraphedForward(base_model, enabled=(device.type == 'cuda' and getattr(args, 'graph_eval', True)))
     with torch.no_grad():
         for idx, (taxonomy_ids, model_ids, data) in enumerate(test_dataloader):
             taxonomy_id = taxonomy_ids[0] if isinstance(taxonomy_ids[0], str) else taxonomy_ids[0].item()
             partial, gt, extra = unpack_batch(dataset_name, data, device)
-            ret = base_model(partial, *extra)
+            ret = forward(partial, *extra)
             coarse_points, dense_points = ret[0], ret[-1]
             vals = [ChamferDisL1(coarse_points, gt), ChamferDisL2(coarse_points, gt),
                     ChamferDisL1(dense_points, gt), ChamferDisL2(dense_points, gt)]

@@ -204,10 +204,16 @@ def check_train_forward_and_loss(device, tol=2e-4):
     assert no_grad == mt["no_grad_params"]
     gsq = {n: float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters() if p.grad is not None}
     total = sum(gsq.values())
-    assert abs(total - mt["grad_sq_norm_total"]) <= 2e-3 * mt["grad_sq_norm_total"], (total, mt["grad_sq_norm_total"])
-    # per-parameter: the model is only piecewise smooth (max-pools over neighbours / tokens, top-k query
-    # selection); rounding-level differences flip a few arg-maxes, which moves an individual parameter's
-    # gradient norm by up to ~1 % (first grouper layer) while the total stays within 0.2 %
+    if os.environ.get("PTOPS_DUMP_GSQ"):
+        import json
+        with open(os.environ["PTOPS_DUMP_GSQ"], "w") as fh:
+            json.dump(gsq, fh)
+    # The model is only piecewise smooth (max-pools over neighbours / tokens, top-k query selection): rounding-level
+    # differences flip a few arg-maxes, which moves an individual parameter's gradient norm by up to ~1 % (first
+    # grouper layer).  Which way the near-ties of this fixture fall depends on the GEMM kernels the BLAS library picks:
+    # two MI355X boxes gave totals of 3.30603 (-0.05 %) and 3.29955 (-0.24 %), each bit-reproducible on its box
+    # (benchmarks/grad_norm_spread.py); the reference value is 3.30754.  Hence 0.5 % on the total, 2 % per parameter.
+    assert abs(total - mt["grad_sq_norm_total"]) <= 5e-3 * mt["grad_sq_norm_total"], (total, mt["grad_sq_norm_total"])
     for n, v in mt["grad_sq_norm_sample"].items():
         assert abs(gsq[n] - v) <= 2e-2 * max(v, 1e-12) + 1e-12, (n, gsq[n], v)
     return l_den.item(), l_rec.item()

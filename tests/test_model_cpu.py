@@ -110,5 +110,7 @@ def test_analytic_normals_eigenvector_matches_eigh():
     assert ((cov @ v.unsqueeze(-1)).squeeze(-1) - w[:, :1] * v).abs().max().item() < 1e-13
     deg = torch.eye(3, dtype=torch.float64).expand(3, 3, 3).clone()
     deg[1] *= 0
-    out = N.smallest_eigenvector_sym3(deg)                    # no defined normal: falls back to eigh, stays finite
+    deg[2, 0, 0] = 2.0                                        # diag(2,1,1): smallest eigenvalue repeated
+    out = N.smallest_eigenvector_sym3(deg)                    # no defined normal: a unit vector of the eigen-plane
     assert torch.isfinite(out).all() and ((out.norm(dim=-1) - 1).abs() < 1e-12).all()
+    assert abs(float(out[2, 0])) < 1e-12                      # orthogonal to the eigenvector of the largest eigenvalue
