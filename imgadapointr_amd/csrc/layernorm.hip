@@ -50,22 +50,30 @@ __global__ __launch_bounds__(kWaves * 64) void ln_fwd_kernel(const float* __rest
     b[i] = in[i] ? ld4(beta + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_c = 1.0f / (float)C;
+  // the loads of row r+1 are issued before the reductions of row r (two dependent wave reductions per row would
+  // otherwise leave the memory pipe idle)
+  float4 nx[NV], nr[NV];
+  auto fetch = [&](long long r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      nx[i] = (in[i] && r < r1) ? ld4(x + r * C + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD) nr[i] = (in[i] && r < r1) ? ld4(res + r * C + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(r0);
   for (long long r = r0; r < r1; ++r) {
-    const float* xr = x + r * C;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      v[i] = in[i] ? ld4(xr + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = nx[i];
       if constexpr (ADD) {
-        if (in[i]) {
-          const float4 a = ld4(res + r * C + 4 * lane + 256 * i);
-          v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
-          st4(sum_out + r * C + 4 * lane + 256 * i, v[i]);
-        }
+        v[i].x += nr[i].x; v[i].y += nr[i].y; v[i].z += nr[i].z; v[i].w += nr[i].w;
+        if (in[i]) st4(sum_out + r * C + 4 * lane + 256 * i, v[i]);
       }
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
+    fetch(r + 1);
     const float mu = wave_sum(s) * inv_c;
     float q = 0.f;
 #pragma unroll
@@ -117,16 +125,29 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
     ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_c = 1.0f / (float)C;
+  float4 nxv[NV], ndv[NV], nev[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](long long r) {   // row r+1 is requested before the reductions of row r
+    const bool ok = r < r1;
+    nmu = ok ? mean[r] : 0.f;
+    nrs = ok ? rstd[r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      nxv[i] = (in[i] && ok) ? ld4(x + r * C + 4 * lane + 256 * i) : make_float4(nmu, nmu, nmu, nmu);
+      ndv[i] = (in[i] && ok) ? ld4(dy + r * C + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD) nev[i] = (in[i] && ok) ? ld4(extra + r * C + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(r0);
   for (long long r = r0; r < r1; ++r) {
-    const float* xr = x + r * C;
-    const float* dr = dy + r * C;
-    const float mu = mean[r], rs = rstd[r];
-    float4 xh[NV], gy[NV];
+    const float mu = nmu, rs = nrs;
+    float4 xh[NV], gy[NV], ev[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const float4 xv = in[i] ? ld4(xr + 4 * lane + 256 * i) : make_float4(mu, mu, mu, mu);
-      const float4 dv = in[i] ? ld4(dr + 4 * lane + 256 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 xv = nxv[i];
+      const float4 dv = ndv[i];
+      if constexpr (ADD) ev[i] = nev[i];
       xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
       gy[i].x = dv.x * g[i].x; gy[i].y = dv.y * g[i].y; gy[i].z = dv.z * g[i].z; gy[i].w = dv.w * g[i].w;
       s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
@@ -135,6 +156,7 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
       ag[i].z = fmaf(dv.z, xh[i].z, ag[i].z); ag[i].w = fmaf(dv.w, xh[i].w, ag[i].w);
       ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
     }
+    fetch(r + 1);
     const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
     float* dxr = dx + r * C;
 #pragma unroll
@@ -146,8 +168,7 @@ __global__ __launch_bounds__(kWaves * 64) void ln_bwd_kernel(const float* __rest
         o.z = rs * (gy[i].z - m1 - xh[i].z * m2);
         o.w = rs * (gy[i].w - m1 - xh[i].w * m2);
         if constexpr (ADD) {
-          const float4 e = ld4(extra + r * C + 4 * lane + 256 * i);
-          o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+          o.x += ev[i].x; o.y += ev[i].y; o.z += ev[i].z; o.w += ev[i].w;
         }
         st4(dxr + 4 * lane + 256 * i, o);
         ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
