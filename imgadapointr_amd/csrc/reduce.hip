@@ -13,12 +13,20 @@ namespace {
 
 constexpr int kRowsPerBlock = 128;
 
+// sum over the 16 row-lanes of a 256-thread workgroup (4 per wave: two shuffles; 4 waves: LDS), fixed order
 __device__ __forceinline__ float4 fold16(float4 (*red)[16], float4 acc, int cx, int ry) {
-  red[ry][cx] = acc;
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+  }
+  if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cx] = acc;
   __syncthreads();
   float4 s = red[0][cx];
 #pragma unroll
-  for (int t = 1; t < 16; ++t) {
+  for (int t = 1; t < 4; ++t) {
     const float4 v = red[t][cx];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 template <int RY>
 __global__ __launch_bounds__(16 * RY) void colsum_final_kernel(const float* __restrict__ partial, int S, int N,
                                                                float* __restrict__ out) {
-  __shared__ float4 red[RY][16];
+  __shared__ float4 red[RY / 4][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int col = (blockIdx.x * 16 + cx) * 4;
   const bool in = col < N;
@@ -71,11 +79,21 @@ __global__ __launch_bounds__(16 * RY) void colsum_final_kernel(const float* __re
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  red[ry][cx] = acc;
+  // a wave holds four row-lanes of every column lane: fold them with two shuffles (fixed order), then the
+  // RY/4 waves through LDS
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+  }
+  if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cx] = acc;
   __syncthreads();
   if (ry == 0 && in) {
     float4 s = red[0][cx];
-    for (int t = 1; t < RY; ++t) {
+#pragma unroll
+    for (int t = 1; t < RY / 4; ++t) {
       const float4 v = red[t][cx];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
