@@ -327,3 +327,88 @@ def check_seg_branch(device, tol=3e-4):
     d_m = compare_ranked(coarse.cpu().numpy(), fine[:, :4096].cpu().numpy(), g["eval_coarse"],
                          g["eval_fine_head"], tol)
     return d_n, d_g, d_m
+
+
+def check_chamfer_baselines(device, tol=1e-4):
+    """PCN, FoldingNet and TopNet (token-major execution, split first layers) vs the reference fixture:
+    state-dict contract, eval forward, train forward (batch statistics), both Chamfer-L2 losses, total gradient
+    norm and the running mean the first BatchNorm accumulates."""
+    import json
+    from imgadapointr_amd.models import build_model_from_cfg
+    from imgadapointr_amd.utils.config import cfg_from_yaml_file
+    g = load("baselines.npz")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = json.load(open(os.path.join(root, "tests", "golden", "baselines_meta.json")))["state_dict"]
+    partial, gt = t(g["partial"], device), t(g["gt_head"], device)
+    report = {}
+
+    def rel(got, want):     # the seeded weights (std 0.1) give outputs of magnitude up to ~200: scale by the range
+        return maxdiff(got.detach().cpu().numpy(), want) / max(1.0, float(np.abs(want).max()))
+    for name in ("PCN", "FoldingNet", "TopNet"):
+        cwd = os.getcwd()
+        os.chdir(root)
+        try:
+            cfg = cfg_from_yaml_file(f"cfgs/PCN_models/{name}.yaml").model
+        finally:
+            os.chdir(cwd)
+        if name == "TopNet":
+            cfg.num_pred = 2048         # the reference cannot construct the 16384-leaf tree (see the generator)
+        model = build_model_from_cfg(cfg)
+        assert {k: list(v.shape) for k, v in model.state_dict().items()} == shapes[name], name
+        model.load_state_dict(seeded_state_dict(model.state_dict(), f"baseline/{name}", std=0.1))
+        model = model.to(device).eval()
+        with torch.no_grad():
+            coarse, fine = model(partial)
+        d_eval = (rel(coarse[:, :512], g[f"{name}_eval_coarse"]), rel(fine[:, :1024], g[f"{name}_eval_fine_head"]))
+        model.train()
+        ret = model(partial)
+        l0, l1 = model.get_loss(ret, gt)
+        (l0 + l1).backward()
+        d_train = rel(ret[1][:, :1024], g[f"{name}_train_fine_head"])
+        want = g[f"{name}_losses"]
+        d_loss = max(abs(l0.item() - want[0]) / abs(want[0]), abs(l1.item() - want[1]) / abs(want[1]))
+        gsq = sum(float((p.grad.double() ** 2).sum()) for p in model.parameters() if p.grad is not None)
+        d_g = abs(gsq - float(g[f"{name}_grad_sq_norm"])) / float(g[f"{name}_grad_sq_norm"])
+        d_rm = maxdiff(model.first_conv[1].running_mean.cpu().numpy(), g[f"{name}_running_mean_first"])
+        report[name] = (d_eval, d_train, d_loss, d_g, d_rm)
+        # Train mode normalises with the statistics of an 8-cloud batch through up to 24 stacked BatchNorms (TopNet's
+        # root layer sees 8 rows), which amplifies rounding: evaluated in float64 this network's gradient norm moves by
+        # 2e-3 relative (4e-3 between two GEMM libraries), so that is the resolution of the gradient comparison.
+        assert max(d_eval) < tol and d_train < 1e-3 and d_loss < 2e-4 and d_g < 1e-2 and d_rm < 1e-5, report
+    return report
+
+
+def check_baseline_forms(device):
+    """Token-major / split-first-layer execution vs the literal channel-first form on the same modules:
+    train-mode outputs, running statistics and every parameter gradient (B = 8, small widths)."""
+    from imgadapointr_amd.models import build_model_from_cfg, pointwise
+    from imgadapointr_amd.utils.config import EasyDict
+    from golden_util import synthetic_batch
+    partial, gt = synthetic_batch(8, 256, 512, seed=51, structured=True)
+    partial, gt = t(partial, device), t(gt, device)
+    report = {}
+    for cfg in (dict(NAME='PCN', num_pred=1024, encoder_channel=1024),
+                dict(NAME='FoldingNet', num_pred=1024, encoder_channel=256),
+                dict(NAME='TopNet', node_feature=8, num_pred=2048, encoder_channel=248, nlevels=6)):
+        runs = []
+        for flag in (True, False):
+            pointwise.TOKEN_MAJOR = flag
+            try:
+                model = build_model_from_cfg(EasyDict(cfg))
+                model.load_state_dict(seeded_state_dict(model.state_dict(), "forms/" + cfg['NAME'], std=0.1))
+                model = model.to(device).train()
+                ret = model(partial)
+                l0, l1 = model.get_loss(ret, gt)
+                (l0 + l1).backward()
+            finally:
+                pointwise.TOKEN_MAJOR = True
+            runs.append((ret[1].detach(), {n: p.grad for n, p in model.named_parameters()},
+                         {n: b for n, b in model.named_buffers() if b.is_floating_point()}))
+        (o1, g1, b1), (o2, g2, b2) = runs
+        d_out = float((o1 - o2).abs().max() / o2.abs().max())
+        gnorm = sum(float(g2[n].double().pow(2).sum()) for n in g2) ** 0.5
+        d_grad = sum(float((g1[n] - g2[n]).double().pow(2).sum()) for n in g2) ** 0.5 / gnorm
+        d_buf = max(float((b1[n] - b2[n]).abs().max() / (1 + b2[n].abs().max())) for n in b2)
+        report[cfg['NAME']] = (d_out, d_grad, d_buf)
+        assert d_out < 2e-4 and d_grad < 2e-3 and d_buf < 1e-5, report
+    return report

@@ -44,6 +44,14 @@ def test_segmentation_branch_matches_reference():
     pc.check_seg_branch("cpu")
 
 
+def test_chamfer_baselines_match_reference():
+    print(pc.check_chamfer_baselines("cpu"))
+
+
+def test_chamfer_baselines_token_major_equals_literal():
+    print(pc.check_baseline_forms("cpu"))
+
+
 def test_state_dict_contract():
     mt = pc.meta()
     model, _ = pc.build_adapointr("cpu")

@@ -35,6 +35,14 @@ def test_train_forward_loss_and_grads_match_reference():
     print(pc.check_train_forward_and_loss("cuda"))
 
 
+def test_chamfer_baselines_match_reference():
+    print(pc.check_chamfer_baselines("cuda"))
+
+
+def test_chamfer_baselines_token_major_equals_literal():
+    print(pc.check_baseline_forms("cuda"))
+
+
 def test_image_fused_model_matches_reference():
     print(pc.check_img_model("cuda"))
 
