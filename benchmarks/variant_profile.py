@@ -1,4 +1,4 @@
-"""Top GPU kernels of one train step of an image variant (torch.profiler)."""
+"""Top GPU kernels of one train step of a model variant (torch.profiler): img | seg | PCN | FoldingNet | TopNet."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ _native.load(); enable_tuned_gemm()
 if len(sys.argv) > 2 and sys.argv[2] == "benchmark":
     torch.backends.cudnn.benchmark = True
 yaml = {"img": "cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml",
-        "seg": "cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml"}[which]
+        "seg": "cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml"}.get(which, f"cfgs/PCN_models/{which}.yaml")
 cfg = cfg_from_yaml_file(yaml)
 torch.manual_seed(0)
 model = build_model_from_cfg(cfg.model).to(dev).train()
@@ -25,9 +25,9 @@ if which == "seg":
     for p in model.base_model.segmentator.parameters():
         p.requires_grad = False
 step = TrainStep(model, builder.build_optimizer(model, cfg), 10, 1)
-B = 16
+B = 16 if which in ("img", "seg") else 32
 partial = (torch.rand(B, 2048, 3) - 0.5).to(dev); gt = (torch.rand(B, 16384, 3) - 0.5).to(dev)
-extra = [torch.rand(B, 3, 224, 224, device=dev)]
+extra = [torch.rand(B, 3, 224, 224, device=dev)] if which in ("img", "seg") else []
 if which == "seg":
     v = torch.zeros(B, 16, device=dev); v[:, 0] = 1; extra.append(v)
 for _ in range(4):

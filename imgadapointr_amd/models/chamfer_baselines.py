@@ -54,7 +54,11 @@ class _PointNetCompletion(nn.Module):
         self.loss_func = ChamferDistanceL2()
 
     def get_loss(self, ret, gt, epoch=0):
-        return self.loss_func(ret[0], gt), self.loss_func(ret[1], gt)
+        loss_coarse = self.loss_func(ret[0], gt)
+        # FoldingNet and TopNet return their one output twice: same value, and summing the pair doubles the gradient
+        # exactly as two evaluations would - without a second 16384^2 Chamfer pass
+        loss_fine = loss_coarse if ret[1] is ret[0] else self.loss_func(ret[1], gt)
+        return loss_coarse, loss_fine
 
     def encode(self, xyz):
         """[B,n,3] -> global code [B,code_width]: max-pool, re-inject the pooled vector per point, max-pool again."""
