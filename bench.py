@@ -154,6 +154,51 @@ class AttentionProbe:
         return out
 
 
+class PrimitiveProbe:
+    """Events around every FPS and kNN launch of one step (algorithmic bytes 12 N + 4 npoint resp.
+    12 (N + S) + 4 S k per cloud; work = (npoint - 1) N point updates resp. S N pair evaluations).  Both are
+    latency / selection bound with the clouds resident on chip, so the HBM fraction is reported for what it is."""
+
+    def __init__(self):
+        self.fps, self.knn = _native.furthest_point_sample, _native.knn
+        self.enabled = False
+        self.rec = {"fps": [], "knn": []}
+
+    def _timed(self, kind, fn, args, nbytes, work):
+        if not self.enabled:
+            return fn(*args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn(*args)
+        e.record()
+        self.rec[kind].append((s, e, nbytes, work))
+        return out
+
+    def furthest_point_sample(self, xyz, npoint):
+        B, N, _ = xyz.shape
+        return self._timed("fps", self.fps, (xyz, npoint), B * (12.0 * N + 4.0 * npoint), B * (npoint - 1.0) * N)
+
+    def knn_call(self, k, xyz, new_xyz):
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        return self._timed("knn", self.knn, (k, xyz, new_xyz), B * (12.0 * (N + S) + 4.0 * S * k), B * 1.0 * S * N)
+
+    def summary(self):
+        out = {}
+        for kind, unit in (("fps", "Gupdate/s"), ("knn", "Gpair/s")):
+            recs = self.rec[kind]
+            if not recs:
+                continue
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            nbytes, work = sum(r[2] for r in recs), sum(r[3] for r in recs)
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out[kind] = {"launches_per_step": len(recs), "ms_per_step": round(ms, 3),
+                         "work_rate": round(work / (ms * 1e-3) / 1e9, 1), "work_unit": unit,
+                         "hbm": {"achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_step": nbytes}}
+        return out
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """The same train step on the host cores through the CPU oracle, B=2 (BASELINE configs[0])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -251,6 +296,8 @@ def main():
     _native.chamfer_forward = probe
     aprobe = AttentionProbe()
     _native.attention_forward, _native.attention_backward = aprobe.forward, aprobe.backward
+    pprobe = PrimitiveProbe()
+    _native.furthest_point_sample, _native.knn = pprobe.furthest_point_sample, pprobe.knn_call
 
     def barrier():
         if world > 1:
@@ -269,18 +316,19 @@ def main():
             note("first step done")
     barrier()
     note("timed region")
-    probe.enabled = aprobe.enabled = True
+    probe.enabled = aprobe.enabled = pprobe.enabled = True
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
         last = step(partial, gt)
-        aprobe.enabled = False          # 132 timing events per step cost ~0.9 ms: only the first timed step carries them
+        aprobe.enabled = pprobe.enabled = False   # ~150 timing events per step cost ~1 ms: only the first timed step carries them
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     probe.enabled = aprobe.enabled = False
     _native.chamfer_forward = probe.orig
     _native.attention_forward, _native.attention_backward = aprobe.fwd, aprobe.bwd
+    _native.furthest_point_sample, _native.knn = pprobe.fps, pprobe.knn
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -302,6 +350,7 @@ def main():
             "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
             "roofline": probe.summary(),
             "roofline_attention": aprobe.summary(1),
+            "roofline_primitives": pprobe.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
