@@ -29,14 +29,27 @@ def timed(fn, n):
 
 
 def main():
+    if len(sys.argv) == 1:
+        # one fresh process per variant: after a bs=32 AdaPoinTr run in the same process the segmentation variant
+        # measured 50 ms instead of 42.6 ms (allocator / workspace state), which says nothing about the variant
+        import subprocess
+        for key in ("AdaPoinTr (PCN)", "ImgResNetEnc", "ImgEncSegDec"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), key], check=True)
+        return
     dev = torch.device("cuda", 0)
     _native.load()
     enable_tuned_gemm()
     os.chdir(ROOT)
     rows = []
+    only = sys.argv[1] if len(sys.argv) > 1 else ""       # substring filter on the variant name
+    if os.environ.get("PTOPS_NOPAD_MHA") == "1":
+        from imgadapointr_amd.models import pctransformer
+        pctransformer.PADDED_HEAD_MFMA_ATTENTION = False
     for name, yaml, B, img, cls in (("AdaPoinTr (PCN)", "cfgs/PCN_models/AdaPoinTr.yaml", 32, False, False),
                                     ("ImgResNetEncAdaPoinTr (ImgPCN)", None, 16, True, False),
                                     ("ImgEncSegDecAdaPoinTr (SegImgPCN)", None, 16, True, True)):
+        if only and only not in name:
+            continue
         if yaml is None:
             sub = "ImgPCN_models" if not cls else "SegImgPCN_models"
             cands = sorted(f for f in os.listdir(os.path.join("cfgs", sub)) if f.endswith(".yaml"))

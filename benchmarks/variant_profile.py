@@ -14,6 +14,9 @@ which = sys.argv[1] if len(sys.argv) > 1 else "img"
 os.chdir(ROOT)
 dev = torch.device("cuda", 0)
 _native.load(); enable_tuned_gemm()
+if len(sys.argv) > 2 and sys.argv[2] == "nopad":
+    from imgadapointr_amd.models import pctransformer as _PT
+    _PT.PADDED_HEAD_MFMA_ATTENTION = False
 if len(sys.argv) > 2 and sys.argv[2] == "benchmark":
     torch.backends.cudnn.benchmark = True
 yaml = {"img": "cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml",

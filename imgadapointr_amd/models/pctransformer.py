@@ -10,10 +10,57 @@ GDANet part embeddings before the encoder output (pctransformer.py:175-199) or a
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import _native
 from .AdaPoinTr import PCTransformer as _PointTrunk
+from .AdaPoinTr import _linear_tokens
 from .image_encoders import ResNet18
-from .Transformer_utils import LayerNorm
+from . import Transformer_utils as TU
+from .Transformer_utils import LayerNorm, add_layer_norm
+
+# True: the fusion layers' 8 x 48-wide heads run on libptops' fp32 MFMA attention (64-wide tiles) by zero-padding the
+# projection WEIGHTS per head (48 -> 64 output rows; the out-projection gets matching zero input columns), so no
+# activation is ever padded or sliced.  Zero dims add nothing to q.k and produce zero output dims: same function.
+PADDED_HEAD_MFMA_ATTENTION = True
+_PAD = 64
+
+
+def _pad_head_rows(w, parts, heads, d):
+    """[parts*heads*d, ...] -> [parts*heads*64, ...] with zero rows after each head's d."""
+    tail = w.shape[1:]
+    w = w.view(parts, heads, d, *tail)
+    return F.pad(w, (0, 0) * len(tail) + (0, _PAD - d)).reshape(parts * heads * _PAD, *tail)
+
+
+def multihead_attention(mha, x, ctx):
+    """`mha(x, ctx, ctx)[0]` of an `nn.MultiheadAttention`, batch-first: x [B,N,E], ctx [B,M,E] -> [B,N,E]."""
+    E, H = mha.embed_dim, mha.num_heads
+    d = E // H
+    B, N, _ = x.shape
+    M = ctx.size(1)
+    if not (PADDED_HEAD_MFMA_ATTENTION and TU.USE_MFMA_ATTENTION and x.is_cuda and x.dtype == torch.float32
+            and _native.backend_for_testing() is None and d <= _PAD and N % 32 == 0 and M % 32 == 0
+            and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None
+            and not mha.add_zero_attn and (mha.dropout == 0.0 or not mha.training)):
+        xs, cs = x.transpose(0, 1), ctx.transpose(0, 1)
+        if mha.batch_first:
+            xs, cs = x, ctx
+        out = mha(xs, cs, cs, need_weights=False)[0]
+        return out if mha.batch_first else out.transpose(0, 1)
+    w = _pad_head_rows(mha.in_proj_weight, 3, H, d)                     # [3*H*64, E]
+    b = _pad_head_rows(mha.in_proj_bias, 3, H, d)
+    scale = d ** -0.5
+    x2, c2 = x.reshape(B * N, E), ctx.reshape(B * M, E)
+    if x is ctx:
+        qkv = _linear_tokens(x2, w, b).view(B, N, 3, H, _PAD)
+        o = TU._MFMASelfAttention.apply(qkv, 0, N, scale)               # [B,N,H,64]
+    else:
+        q = _linear_tokens(x2, w[:H * _PAD], b[:H * _PAD]).view(B, N, H, _PAD).transpose(1, 2)
+        k, v = _linear_tokens(c2, w[H * _PAD:], b[H * _PAD:]).view(B, M, 2, H, _PAD).permute(2, 0, 3, 1, 4).unbind(0)
+        o = TU._MFMAAttention.apply(q, k, v, 0, M, scale)
+    wo = F.pad(mha.out_proj.weight.view(E, H, d), (0, _PAD - d)).reshape(E, H * _PAD)
+    return _linear_tokens(o.reshape(B * N, H * _PAD), wo, mha.out_proj.bias).view(B, N, E)
 
 
 class PCTransformer(_PointTrunk):
@@ -50,35 +97,32 @@ class PCTransformer(_PointTrunk):
             setattr(self, f'layer_norm_{tag}{i}', LayerNorm(self.img_dim))
 
     def _fuse(self, x, ctx, tag):
-        """x [N,B,C] tokens, ctx [M,B,C] context (sequence-first, as nn.MultiheadAttention expects)."""
-        g = lambda name: getattr(self, f'{name}_{tag}' if not name.startswith('layer_norm') else name)  # noqa: E731
-        ln = lambda i: getattr(self, f'layer_norm_{tag}{i}')  # noqa: E731
-        out, _ = getattr(self, f'cross_attn_{tag}1')(x, ctx, ctx, need_weights=False)
-        x = ln(1)(out + x)
-        out, _ = getattr(self, f'self_attn_{tag}1')(x, x, x, need_weights=False)
-        x = ln(2)(out + x)
+        """x [B,N,C] tokens, ctx [B,M,C] context: five post-norm attention layers (pctransformer.py:148-172)."""
+        att = lambda kind, n, q, kv: multihead_attention(getattr(self, f'{kind}_{tag}{n}'), q, kv)  # noqa: E731
+        ln = lambda i, out, res: add_layer_norm(out, res, getattr(self, f'layer_norm_{tag}{i}'))[1]  # noqa: E731
+        x = x.contiguous()
+        ctx = ctx.contiguous()
+        x = ln(1, att('cross_attn', 1, x, ctx), x)
+        x = ln(2, att('self_attn', 1, x, x), x)
         skip = x
-        out, _ = getattr(self, f'cross_attn_{tag}2')(x, ctx, ctx, need_weights=False)
-        x = ln(3)(out + x)
-        out, _ = getattr(self, f'self_attn_{tag}2')(x, x, x, need_weights=False)
-        x = ln(4)(out + x)
-        out, _ = getattr(self, f'cross_attn_{tag}3')(x, skip, skip, need_weights=False)
-        return ln(5)(out + x)
+        x = ln(3, att('cross_attn', 2, x, ctx), x)
+        x = ln(4, att('self_attn', 2, x, x), x)
+        return ln(5, att('cross_attn', 3, x, skip), x)
 
     def _seg_tokens(self, points, cls_vec):
-        """points [B,N,3] -> GDANet part embeddings as [N,B,384] tokens."""
+        """points [B,N,3] -> GDANet part embeddings as [B,N,384] tokens."""
         from .segmentation.normals import estimate_pointcloud_normals
         normals = estimate_pointcloud_normals(points, 30, disambiguate_directions=False)
         seg_emb, _ = self.segmentator(points.transpose(1, 2), normals, cls_vec)
-        return self.get_better_seg_size(seg_emb.transpose(1, 2).transpose(0, 1))
+        return self.get_better_seg_size(seg_emb.transpose(1, 2))
 
     # hooks called by the point trunk ---------------------------------------------------------
     def fuse_encoder_tokens(self, x, coor, img, cls_vec):
         if self.use_img:
-            img_feat = self.get_better_img_size(self.im_encoder(img)).transpose(0, 1)   # [256,B,384]
-            x = self._fuse(x.transpose(0, 1), img_feat, 'img').transpose(0, 1)
+            img_feat = self.get_better_img_size(self.im_encoder(img))                   # [B,256,384]
+            x = self._fuse(x, img_feat, 'img')
         if self.use_seg and getattr(self.config, 'seg_before_enc', False) and cls_vec is not None:
-            x = self._fuse(x.transpose(0, 1), self._seg_tokens(coor, cls_vec), 'seg').transpose(0, 1)
+            x = self._fuse(x, self._seg_tokens(coor, cls_vec), 'seg')
         return x
 
     def fuse_decoder_tokens(self, q, coarse, denoise_length, cls_vec):
@@ -86,7 +130,7 @@ class PCTransformer(_PointTrunk):
             return q
         n = coarse.size(1) - denoise_length            # only the real queries are enhanced
         seg = self._seg_tokens(coarse[:, :n], cls_vec)
-        fused = self._fuse(q[:, :n].transpose(0, 1), seg, 'seg').transpose(0, 1)
+        fused = self._fuse(q[:, :n], seg, 'seg')
         return fused if denoise_length == 0 else torch.cat([fused, q[:, n:]], dim=1)
 
     def forward(self, xyz, img=None, cls_vec=None, denoise_noise=None):

@@ -580,3 +580,42 @@ def test_gelu_backward_with_column_sums(native):
     (want,) = torch.autograd.grad(torch.nn.functional.gelu(x64), x64, gg.double())
     assert (dpre.double() - want).abs().max().item() < 2e-6
     assert (cs.double() - want.sum(0)).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("self_attention", [True, False])
+def test_padded_head_multihead_attention_equals_module(native, self_attention):
+    """nn.MultiheadAttention(384, 8) (48-wide heads) through the 64-wide MFMA attention with zero-padded projection
+    weights vs the module's own forward, in float64: output and every gradient."""
+    from imgadapointr_amd.models import pctransformer as PT
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    B, N, M, E = 8, 256, 256 if self_attention else 512, 384
+    mha = torch.nn.MultiheadAttention(E, 8).to(dev)
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.1)
+        mha.out_proj.bias.normal_(0, 0.1)
+    x = torch.randn(B, N, E, device=dev, requires_grad=True)
+    ctx = x if self_attention else torch.randn(B, M, E, device=dev, requires_grad=True)
+    up = torch.randn(B, N, E, device=dev)
+
+    y = PT.multihead_attention(mha, x, ctx)
+    y.backward(up)
+    got = [y.detach()] + [p.grad.clone() for p in (x, *((ctx,) if not self_attention else ()), *mha.parameters())]
+
+    ref = torch.nn.MultiheadAttention(E, 8).to(dev).double()
+    ref.load_state_dict({k: v.double() for k, v in mha.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    cd = xd if self_attention else ctx.detach().double().requires_grad_(True)
+    yd = ref(xd.transpose(0, 1), cd.transpose(0, 1), cd.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+    yd.backward(up.double())
+    want = [yd.detach()] + [p.grad for p in (xd, *((cd,) if not self_attention else ()), *ref.parameters())]
+    for g, w in zip(got, want):
+        err = float((g.double() - w).abs().max() / w.abs().max())
+        assert err < 2e-5, err
+    # the switch really selects the other path
+    PT.PADDED_HEAD_MFMA_ATTENTION = False
+    try:
+        y2 = PT.multihead_attention(mha, x, ctx)
+    finally:
+        PT.PADDED_HEAD_MFMA_ATTENTION = True
+    assert float((y2 - y).abs().max()) < 1e-4 and not torch.equal(y2, y)
