@@ -619,3 +619,47 @@ def test_padded_head_multihead_attention_equals_module(native, self_attention):
     finally:
         PT.PADDED_HEAD_MFMA_ATTENTION = True
     assert float((y2 - y).abs().max()) < 1e-4 and not torch.equal(y2, y)
+
+
+def test_full_size_properties(native):
+    """BASELINE sizes (B = 32, 2048 -> 16384), where the CPU oracle would take minutes: properties instead.
+    Chamfer: two independent algorithms (brute force, pruned sweep) agree bit for bit, the two directions are each
+    other's mirror, distances are invariant under a permutation of the target and the indices follow it, and the
+    returned index reproduces the returned distance.  FPS: prefix property and first index.  kNN: the k-th distance
+    equals torch.topk's on the reference's own expansion-form matrix up to its rounding, neighbours are sorted."""
+    torch.manual_seed(7)
+    B, n, m = 32, 16384, 16384
+    a = torch.rand(B, n, 3, device="cuda") - 0.5
+    b = a[:, torch.randperm(n, device="cuda")] + torch.randn(B, m, 3, device="cuda") * 0.01
+    brute = native.chamfer_forward(a, b, algorithm=native.CHAMFER_BRUTE)
+    sweep = native.chamfer_forward(a, b, algorithm=native.CHAMFER_SWEEP)
+    assert all(torch.equal(x, y) for x, y in zip(brute, sweep))
+    d1, d2, i1, i2 = brute
+    m1, m2, j1, j2 = native.chamfer_forward(b, a, algorithm=native.CHAMFER_BRUTE)
+    assert torch.equal(d1, m2) and torch.equal(d2, m1) and torch.equal(i1, j2) and torch.equal(i2, j1)
+    # the index reproduces the distance (same subtraction order as the kernel: query - target)
+    near = torch.gather(b, 1, i1.long().unsqueeze(-1).expand(-1, -1, 3))
+    diff = a - near
+    recomputed = diff[..., 0] * diff[..., 0] + (diff[..., 1] * diff[..., 1] + diff[..., 2] * diff[..., 2])
+    assert float((recomputed - d1).abs().max()) <= 1e-9 + 4 * float(d1.max()) * 2 ** -23
+    perm = torch.randperm(m, device="cuda")
+    p1, p2, pi1, pi2 = native.chamfer_forward(a, b[:, perm], algorithm=native.CHAMFER_SWEEP)
+    assert torch.equal(p1, d1) and torch.equal(p2, d2[:, perm])
+    same = perm[pi1.long()] == i1.long()                       # an exact distance tie may resolve to another index
+    assert float(same.float().mean()) > 0.9999
+
+    part = torch.rand(B, 2048, 3, device="cuda") - 0.5
+    f512 = native.furthest_point_sample(part, 512)
+    f64 = native.furthest_point_sample(part, 64)
+    assert torch.equal(f512[:, :64], f64) and bool((f512[:, 0] == 0).all())
+    assert all(len(set(row.tolist())) == 512 for row in f512[:4].cpu())
+
+    k = 16
+    idx = native.knn(k, part, part)                            # [B,2048,16], sorted by (distance, index)
+    nb = torch.gather(part.unsqueeze(1).expand(-1, 2048, -1, -1), 2, idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+    dist = ((nb - part.unsqueeze(2)) ** 2).sum(-1)
+    # (the kernel orders by the reference's expansion-form distance; direct differences agree to its rounding)
+    assert bool((dist[..., 1:] >= dist[..., :-1] - 2e-6).all()) and bool((idx[..., 0] == torch.arange(2048, device="cuda")).all())
+    sq = -2 * part @ part.transpose(1, 2) + (part ** 2).sum(-1)[:, :, None] + (part ** 2).sum(-1)[:, None, :]
+    kth = sq.topk(k, dim=-1, largest=False).values.max(-1).values
+    assert float((kth - dist[..., -1]).abs().max()) < 5e-6
