@@ -268,7 +268,11 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    force_ddp = os.environ.get("PTOPS_BENCH_FORCE_DDP") == "1"
+    # PTOPS_BENCH_FORCE_DDP=1 under torch.distributed.run with ONE rank: the real RCCL call sequence (broadcasts, async
+    # AVG all-reduces from the gradient hooks, waits) on a one-GPU box.  Never the default, never a scaling number.
+    single_rank_rccl = force_ddp and world == 1 and "MASTER_ADDR" in os.environ and not rehearsal
+    if world > 1 or single_rank_rccl:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group(backend="gloo")
@@ -283,7 +287,7 @@ def main():
     model.train()
     # PTOPS_BENCH_FORCE_DDP=1 wraps the model at N=1 too (hooks + bucket packing, no collective): a way to see
     # the data-parallel bookkeeping overhead on a one-GPU box.  Never the default.
-    wrapped = FlatDDP(model) if (world > 1 or os.environ.get("PTOPS_BENCH_FORCE_DDP") == "1") else model
+    wrapped = FlatDDP(model, single_rank_collectives=single_rank_rccl) if (world > 1 or force_ddp) else model
     optimizer = builder.build_optimizer(wrapped, cfg)
     step = TrainStep(wrapped, optimizer, getattr(cfg, "grad_norm_clip", 10), 1)
 
@@ -300,7 +304,7 @@ def main():
     _native.furthest_point_sample, _native.knn = pprobe.furthest_point_sample, pprobe.knn_call
 
     def barrier():
-        if world > 1:
+        if world > 1 or single_rank_rccl:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -355,7 +359,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or single_rank_rccl:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -25,11 +25,14 @@ import torch.nn as nn
 
 
 class FlatDDP(nn.Module):
-    def __init__(self, module, bucket_mb=64, process_group=None):
+    def __init__(self, module, bucket_mb=64, process_group=None, single_rank_collectives=False):
+        """`single_rank_collectives`: issue the broadcasts / all-reduces even in a world of one rank (a way to run the
+        exact RCCL call sequence on a one-GPU box, tests/test_runner_gpu.py); off, a single rank skips them."""
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._collective = self.world_size > 1 or (single_rank_collectives and dist.is_initialized())
         self.bucket_bytes = int(bucket_mb * 1024 * 1024)
         self._buckets = None       # list of dict(flat, params, views, pending, handle, packed)
         self._param_bucket = {}
@@ -37,9 +40,9 @@ class FlatDDP(nn.Module):
         self._discovered = False
         self._sync = True
         # RCCL averages inside the collective; gloo (CPU tests) only sums, so divide afterwards there
-        self._avg_in_collective = (self.world_size > 1 and dist.get_backend(process_group) == "nccl")
+        self._avg_in_collective = (self._collective and dist.get_backend(process_group) == "nccl")
         # identical start: rank 0's parameters and buffers everywhere (as DDP does at wrap time)
-        if self.world_size > 1:
+        if self._collective:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=process_group)
 
@@ -93,7 +96,7 @@ class FlatDDP(nn.Module):
 
     def _launch(self, b, async_op=True):
         self._pack(b)
-        if self.world_size > 1:
+        if self._collective:
             op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
             b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.process_group, async_op=async_op)
 
@@ -126,13 +129,13 @@ class FlatDDP(nn.Module):
             self._discovered = True
             for b in self._buckets:
                 self._launch(b, async_op=False)
-                if self.world_size > 1 and not self._avg_in_collective:
+                if self._collective and not self._avg_in_collective:
                     b["flat"].div_(self.world_size)
             return
         for b in self._buckets:
             if not b["packed"]:          # some hook did not fire, or averaging was off during backward
                 self._launch(b)
-        if self.world_size > 1:
+        if self._collective:
             for b in self._buckets:
                 if b["handle"] is not None:
                     b["handle"].wait()

@@ -69,3 +69,16 @@ def test_graphed_forward_matches_eager(native):
     x = torch.rand(1, 2048, 3, device="cuda") - 0.5
     out = gf(x)                                                   # gradients enabled: plain eager call
     assert gf.replays == 4 and out[-1].requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_flat_ddp_call_sequence_on_rccl(native):
+    """The multi-GPU path's RCCL calls, run with one rank on this box (tests/rccl_single_rank.py); a child process
+    with its own time limit, so a wedged rendezvous fails instead of hanging the suite."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_PORT="29637")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "rccl single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
