@@ -7,8 +7,9 @@ Interface of models/Transformer_utils.py of the reference:
 The deformable-attention variants (Transformer_utils.py:161-777, 871-1044) are reachable only
 through block tokens no YAML selects and are out of scope.
 
-kNN and the gathers run on libptops (csrc/knn.hip, gather.hip); GEMMs / softmax stay on
-PyTorch-ROCm (hipBLASLt MFMA).
+kNN, the gathers, head-dim-64 attention (forward and backward), LayerNorm (+ fused residual add), GELU backward
+and the bias-gradient column sums run on libptops (csrc/knn.hip, gather.hip, attention.hip, layernorm.hip,
+activation.hip, reduce.hip); the dense GEMMs stay on PyTorch-ROCm (hipBLASLt / rocBLAS MFMA kernels).
 """
 import torch
 import torch.nn as nn
@@ -24,12 +25,11 @@ FUSED_GRAPH_ATTENTION = True
 # Attention evaluation: F.scaled_dot_product_attention (True) or the reference's explicit
 # softmax(q k^T) v chain (False).
 USE_SDPA = True
-# Forward of head-dim-64 attention on libptops' fp32 MFMA kernel (csrc/attention.hip), backward on
-# PyTorch-ROCm's memory-efficient attention backward (aten::_efficient_attention_backward), which
-# consumes the same (out, logsumexp) pair.  Falls back to SDPA for shapes the kernel does not cover.
+# Head-dim-64 attention on libptops' fp32 MFMA kernels (csrc/attention.hip); the backward variant is chosen below.
+# Falls back to SDPA for shapes the kernels do not cover (token counts that are not multiples of 32).
 USE_MFMA_ATTENTION = True
 # "fused": single-pass MFMA backward (5 GEMMs); "split": the dq + dk/dv kernel pair (7 GEMMs);
-# False: aten::_efficient_attention_backward
+# False: PyTorch-ROCm's aten::_efficient_attention_backward, which consumes the same (out, logsumexp) pair
 USE_MFMA_ATTENTION_BWD = "fused"
 _LN2 = 0.6931471805599453
 _bias_cache = {}
@@ -355,9 +355,10 @@ class _MFMAAttention(torch.autograd.Function):
 
 
 class _MFMASelfAttention(torch.autograd.Function):
-    """Self attention on the PACKED projection qkv [B,N,3,h,64]: the backward asks
-    aten::_efficient_attention_backward for dq/dk/dv in one [B,N,3,h,64] allocation and returns it as the
-    gradient of qkv, so autograd does not have to zero-fill and scatter three slices per layer."""
+    """Self attention on the PACKED projection qkv [B,N,3,h,64]: the backward writes dq/dk/dv straight into one
+    [B,N,3,h,64] allocation (strided views handed to the MFMA backward kernel; with USE_MFMA_ATTENTION_BWD off,
+    aten::_efficient_attention_backward's shared-storage output) and returns it as the gradient of qkv, so autograd
+    does not have to zero-fill and scatter three slices per layer."""
 
     @staticmethod
     def forward(ctx, qkv, split_q, limit_k, scale):
