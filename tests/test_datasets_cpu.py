@@ -115,3 +115,62 @@ def test_transforms():
     assert np.allclose(m(pts.copy(), 0.3), pts * [-1, 1, 1])
     assert np.allclose(m(pts.copy(), 0.6), pts * [1, 1, -1])
     assert np.allclose(m(pts.copy(), 0.9), pts)
+
+
+def _lzf_compress(data):
+    """A small greedy liblzf-format encoder for the test (literal runs <= 32, back references found by a 3-byte hash)."""
+    out, lit, i, n, table = bytearray(), bytearray(), 0, len(data), {}
+
+    def flush():
+        for s in range(0, len(lit), 32):
+            chunk = lit[s:s + 32]
+            out.append(len(chunk) - 1)
+            out.extend(chunk)
+        lit.clear()
+
+    while i < n:
+        key = bytes(data[i:i + 3])
+        ref = table.get(key) if len(key) == 3 else None
+        if len(key) == 3:
+            table[key] = i
+        if ref is not None and 0 < i - ref <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[ref + length] == data[i + length]:
+                length += 1
+            flush()
+            off, l2 = i - ref - 1, length - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (off >> 8))
+            else:
+                out.append((7 << 5) | (off >> 8))
+                out.append(l2 - 7)
+            out.append(off & 255)
+            i += length
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def test_pcd_reader_binary_compressed(tmp_path):
+    """PCL's DATA binary_compressed: LZF over a field-major block, with an extra non-xyz field in between."""
+    from imgadapointr_amd.utils.io_module import IO, lzf_decompress
+    # the decoder on its own: literals, a plain back reference and an overlapping (run-length) one
+    assert lzf_decompress(bytes([2]) + b"abc" + bytes([(1 << 5) | 0, 2]), 6) == b"abcabc"
+    assert lzf_decompress(bytes([0]) + b"a" + bytes([(7 << 5) | 0, 1, 0]), 11) == b"a" * 11
+    with pytest.raises(ValueError):
+        lzf_decompress(bytes([(1 << 5) | 0, 5]), 3)
+    rng = np.random.default_rng(3)
+    pts = np.round(rng.random((700, 3)) * 64).astype(np.float32) / 64 - 0.5      # repetitive bytes: real back references
+    rgb = rng.integers(0, 2 ** 24, size=700).astype("<u4")
+    raw = pts[:, 0].astype("<f4").tobytes() + rgb.tobytes() + pts[:, 1].astype("<f4").tobytes() + pts[:, 2].astype("<f4").tobytes()
+    comp = _lzf_compress(raw)
+    assert len(comp) < len(raw) and lzf_decompress(comp, len(raw)) == raw
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x rgb y z\nSIZE 4 4 4 4\nTYPE F U F F\n"
+            "COUNT 1 1 1 1\nWIDTH 700\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 700\nDATA binary_compressed\n")
+    with open(tmp_path / "c.pcd", "wb") as fh:
+        fh.write(head.encode())
+        fh.write(np.asarray([len(comp), len(raw)], dtype="<u4").tobytes())
+        fh.write(comp)
+    assert np.array_equal(IO.get(str(tmp_path / "c.pcd")).astype(np.float32), pts)
