@@ -61,6 +61,16 @@ def main():
             o = TU._MFMAAttention.apply(qr, kr, vr, split, limit, scale)
             tb[nb] = timeit(lambda: torch.autograd.grad(o, (qr, kr, vr), go, retain_graph=True))
         TU.USE_MFMA_ATTENTION_BWD = "fused"
+        qsplit = {}
+        for B2 in (32, 16):                       # query-range split of the single-pass kernel: forced off / on
+            q2, k2, v2 = (t[:B2].detach().requires_grad_(True) for t in (q, k, v))
+            for n in ("1", "2"):
+                os.environ["PTOPS_ATTN_QSPLIT"] = n
+                o2 = TU._MFMAAttention.apply(q2, k2, v2, split, limit, scale)
+                qsplit[(B2, n)] = timeit(lambda: torch.autograd.grad(o2, (q2, k2, v2), go[:B2], retain_graph=True)) * 1e3
+        os.environ.pop("PTOPS_ATTN_QSPLIT")
+        print(f"{name:18s} single-pass backward, query split off/on: B=32 {qsplit[(32, '1')]:.1f} / {qsplit[(32, '2')]:.1f} us   "
+              f"B=16 {qsplit[(16, '1')]:.1f} / {qsplit[(16, '2')]:.1f} us")
         keys_eff = (split * limit + (Nq - split) * Nk) if split else Nq * Nk
         print(f"{name:18s} backward: single-pass {tb['fused']*1e3:7.1f} us ({10.0*keys_eff*d*B*H/tb['fused']/1e9:6.1f} TF/s)  "
               f"dq + dk/dv pair {tb['split']*1e3:7.1f} us ({14.0*keys_eff*d*B*H/tb['split']/1e9:6.1f} TF/s executed)  aten {tb[False]*1e3:7.1f} us")

@@ -22,6 +22,8 @@
 //                   ds_read_b32 across dims).
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "ptops_common.h"
 
 namespace {
@@ -522,7 +524,8 @@ constexpr int fused_lds_floats(int fw) { return 2 * kTK * kLd + 2 * kTK + fw * k
 
 struct AttnFusedArgs {
   AttnBwdArgs a;
-  float* dq_partial;  // [n_kb, B*H, Nq, 64] when n_kb > 1
+  float* dq_partial;   // [n_kb, B*H, Nq, 64] when n_kb > 1
+  float* dkv_partial;  // [n_qs, B*H, Nk, 2, 64] when the query tiles of a key block are split over n_qs workgroups
   int n_kb;
 };
 
@@ -539,8 +542,11 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
   float* sT = sW + wave * kWaveLds;
   float* sK = sT + kTK * kTs;
   const int j = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
-  const int kb = blockIdx.x;
+  // grid = (B*H, n_kb, query splits): key-block-major dispatch order, so the short workgroups of the last block
+  // (keys past limit_k, seen by the denoise queries only) start after every long one and fill the tail of the launch
+  const int bh = blockIdx.x, b = bh / a.H, head = bh % a.H;
+  const int kb = blockIdx.y;
+  const int n_bh = gridDim.x;
   const int k0 = (kb * kFW + wave) * 32;
   const bool active = k0 < a.Nk;
   const float* qb = a.q + b * a.q_sb + head * a.q_sh;
@@ -620,7 +626,12 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
   // this wave's 16x16 block(s) of the dQ tile: blocks wave, wave + kFW, ... of the 8
   const int li = lane & 15, lk = lane >> 4;
 
-  const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
+  // gridDim.z workgroups share the query tiles of a key block (each owns a contiguous range and its own dk/dv partial)
+  const int n_qs = gridDim.z;
+  const int t_first = blk_qstart / kTK, t_last = a.Nq / kTK;
+  const int t_per = (t_last - t_first + n_qs - 1) / n_qs;
+  const int t_begin = t_first + (int)blockIdx.z * t_per;
+  const int t_end = min(t_last, t_begin + t_per);
   if (t_begin < t_end) {
     fetch_tile(t_begin * kTK);
     store_tile();
@@ -708,7 +719,7 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
         if (fa.n_kb == 1)
           a.dq[b * a.dq_sb + head * a.dq_sh + (long long)q * a.dq_sn + bd + li] = g[r] * a.scale;
         else
-          fa.dq_partial[(((long long)kb * gridDim.y + bh) * a.Nq + q) * kD + bd + li] = g[r];
+          fa.dq_partial[(((long long)kb * n_bh + bh) * a.Nq + q) * kD + bd + li] = g[r];
       }
     }
     __syncthreads();  // all reads of sQ / sO / sL / the scratches done
@@ -717,9 +728,35 @@ __global__ __launch_bounds__(kFW * 64, 2) void attn_bwd_fused_kernel(AttnFusedAr
   }
 
   if (active) {
-    store_dim_major(a.dk + b * a.dk_sb + head * a.dk_sh + (long long)(k0 + j) * a.dk_sn, dk0, dk1, h, a.scale);
-    store_dim_major(a.dv + b * a.dv_sb + head * a.dv_sh + (long long)(k0 + j) * a.dv_sn, dv0, dv1, h, 1.0f);
+    if (n_qs == 1) {
+      store_dim_major(a.dk + b * a.dk_sb + head * a.dk_sh + (long long)(k0 + j) * a.dk_sn, dk0, dk1, h, a.scale);
+      store_dim_major(a.dv + b * a.dv_sb + head * a.dv_sh + (long long)(k0 + j) * a.dv_sn, dv0, dv1, h, 1.0f);
+    } else {
+      float* pk = fa.dkv_partial + ((((long long)blockIdx.z * n_bh + bh) * a.Nk + (k0 + j)) * 2) * kD;
+      store_dim_major(pk, dk0, dk1, h, a.scale);
+      store_dim_major(pk + kD, dv0, dv1, h, 1.0f);
+    }
   }
+}
+
+// dk / dv = sum over the query ranges (fixed order); one float4 of one (bh, key, k|v) row per thread
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const float* __restrict__ partial, int n_qs, long long BH, int H,
+                                                              int Nk, float* __restrict__ dk, float* __restrict__ dv,
+                                                              long long dk_sb, long long dk_sh, long long dk_sn,
+                                                              long long dv_sb, long long dv_sh, long long dv_sn) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= BH * Nk * 32) return;
+  const int c4 = (int)(e & 15) * 4, which = (int)(e >> 4) & 1;
+  const long long row = e >> 5;  // bh * Nk + key
+  const int key = (int)(row % Nk);
+  const long long bh = row / Nk;
+  const long long stride = BH * Nk * 2 * kD;
+  const float* src = partial + (row * 2 + which) * kD + c4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+  for (int s = 1; s < n_qs; ++s) acc += *reinterpret_cast<const f32x4*>(src + s * stride);
+  const long long b = bh / H, head = bh % H;
+  float* dst = which ? dv + b * dv_sb + head * dv_sh + (long long)key * dv_sn : dk + b * dk_sb + head * dk_sh + (long long)key * dk_sn;
+  *reinterpret_cast<f32x4*>(dst + c4) = acc;
 }
 
 // dq = scale * sum over the key blocks that reach the query (fixed order)
@@ -848,10 +885,39 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
 // workgroups per CU) only where they tile the keys exactly and balance the CUs better (512 keys: 323 vs 385 us).
 static int fused_waves(int Nk) { return (Nk > 256 && Nk % 256 == 0) ? 4 : 8; }
 
+// Splitting the query tiles of every key block over two workgroups (each with its own dk/dv partial, summed by
+// attn_dkv_reduce_kernel, ~40 us at the training shape) pays in two situations, both measured on the 8-wave kernel
+// (benchmarks/attention_bench.py, attention_occupancy_probe.py; one workgroup per CU, launches run in whole rounds of
+// 256 workgroups):
+//  * the unsplit launch leaves at least half of the CU slots empty - the batch-16 model variants
+//    (96 blocks: 201 -> 124 us for the 576 x 256 cross-attention);
+//  * it needs >= 2 rounds and halves fill them better - the batch-32 decoder self-attention
+//    (2 x 192 long blocks = 1.5 rounds -> 3 half rounds: 424 -> 394 us).
+// It loses where the halves fill no better (192 blocks: 207 -> 229 us) and with the 4-wave kernel, whose workgroups
+// share CUs in pairs.  PTOPS_ATTN_QSPLIT=1|2 overrides the choice for benchmarking.
+static int fused_query_splits(long long BH, int Nq, int Nk, int limit_k) {
+  const int fw = fused_waves(Nk);
+  const long long slots = (long long)ptops::kNumCU * (fw == 8 ? 1 : 2);
+  const long long blocks = BH * ptops::ceil_div(limit_k < Nk ? limit_k : Nk, fw * 32);   // the others see few queries
+  if (Nq / kTK < 8) return 1;
+  if (const char* force = getenv("PTOPS_ATTN_QSPLIT")) {
+    if (force[0] == '1' || force[0] == '2') return force[0] - '0';
+  }
+  if (Nq / kTK < 16) return 1;
+  if (2 * blocks <= slots) return 2;
+  const long long r1 = (blocks + slots - 1) / slots, r2x2 = (2 * blocks + slots - 1) / slots;   // rounds, 2 x half rounds
+  return (fw == 8 && r1 >= 2 && 5 * r2x2 <= 8 * r1) ? 2 : 1;
+}
+
+static size_t fused_dq_partial_floats(int B, int H, int Nq, int Nk) {
+  const int n_kb = ptops::ceil_div(Nk, fused_waves(Nk) * 32);
+  return n_kb > 1 ? (size_t)n_kb * B * H * Nq * kD : 64;
+}
+
 PTOPS_API size_t ptops_attention_backward_fused_workspace_bytes(int B, int H, int Nq, int Nk) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return 0;
-  const int n_kb = ptops::ceil_div(Nk, fused_waves(Nk) * 32);
-  return n_kb > 1 ? sizeof(float) * (size_t)n_kb * B * H * Nq * kD : 16;
+  // dq partials + room for two dk/dv partials (whether they are used depends on the mask split of the call)
+  return sizeof(float) * (fused_dq_partial_floats(B, H, Nq, Nk) + (size_t)2 * B * H * Nk * 2 * kD);
 }
 
 PTOPS_API int ptops_attention_backward_fused(const float* q, const float* k, const float* v, const float* out,
@@ -892,18 +958,27 @@ PTOPS_API int ptops_attention_backward_fused(const float* q, const float* k, con
   const int fw = fused_waves(Nk);
   fa.n_kb = ptops::ceil_div(Nk, fw * 32);
   fa.dq_partial = (float*)workspace;
+  fa.dkv_partial = (float*)workspace + fused_dq_partial_floats(B, H, Nq, Nk);
+  const int n_qs = fused_query_splits((long long)B * H, Nq, Nk, (split_q > 0 && limit_k < Nk) ? limit_k : Nk);
   const size_t lds = sizeof(float) * (size_t)fused_lds_floats(fw);
   // up to 128 KB of dynamic LDS: above the 64 KB default cap (idempotent per-function setting)
   if (fw == 8) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(fa.n_kb, B * H), dim3(512), lds, stream, fa);
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(B * H, fa.n_kb, n_qs), dim3(512), lds, stream, fa);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, dim3(fa.n_kb, B * H), dim3(256), lds, stream, fa);
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, dim3(B * H, fa.n_kb, n_qs), dim3(256), lds, stream, fa);
   }
   int rc = ptops::check_launch("attn_bwd_fused_kernel");
+  if (rc == PTOPS_OK && n_qs > 1) {
+    const long long vec2 = (long long)B * H * Nk * 32;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((vec2 + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)fa.dkv_partial, n_qs, (long long)B * H, H, Nk, dk, dv, a.dk_sb, a.dk_sh, a.dk_sn, a.dv_sb,
+                       a.dv_sh, a.dv_sn);
+    rc = ptops::check_launch("attn_dkv_reduce_kernel");
+  }
   if (rc != PTOPS_OK || fa.n_kb == 1) return rc;
   const long long vec = (long long)B * H * Nq * 16;
   hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((vec + 255) / 256)), dim3(256), 0, stream,

@@ -308,6 +308,35 @@ def test_attention_forward_and_backward(native, Nq, Nk, split, limit, bwd, monke
     assert (g[1][:, :, 1].double() - gv.permute(0, 2, 1, 3)).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("B,Nq,Nk,split,limit", [(32, 576, 576, 512, 512), (32, 576, 256, 0, 256), (32, 256, 256, 0, 256),
+                                                  (16, 256, 256, 0, 256), (32, 512, 512, 0, 512)])
+def test_attention_backward_at_training_batch(native, B, Nq, Nk, split, limit, monkeypatch):
+    """The production launch configurations (192 / 96 heads) of the single-pass kernel - automatic choice, query-range
+    split forced off and forced on - against the independent dq + dk/dv kernel pair."""
+    torch.manual_seed(B + Nq)
+    H, d = 6, 64
+    q = torch.randn(B, H, Nq, d, device="cuda")
+    k = torch.randn(B, H, Nk, d, device="cuda")
+    v = torch.randn(B, H, Nk, d, device="cuda")
+    scale = d ** -0.5
+    out, lse = native.attention_forward(q, k, v, split, limit, scale)
+    go = torch.randn_like(out)
+    res = []
+    for fused, qsplit in ((False, None), (True, None), (True, "1"), (True, "2")):
+        dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
+        if qsplit is not None:
+            monkeypatch.setenv("PTOPS_ATTN_QSPLIT", qsplit)
+        native.attention_backward(q, k, v, out, go, lse, split, limit, scale, dq, dk, dv, fused=fused)
+        monkeypatch.delenv("PTOPS_ATTN_QSPLIT", raising=False)
+        res.append((dq, dk, dv))
+    for got in res[1:]:
+        for a, b in zip(got, res[0]):
+            assert bool(torch.isfinite(a).all())
+            assert float((a - b).abs().max()) < 3e-5 * max(1.0, float(b.abs().max()))
+    # the split only changes where dk / dv are summed: dq is bit-identical, and forcing it on/off is deterministic
+    assert torch.equal(res[2][0], res[3][0])
+
+
 def test_attention_rejects_unsupported_shapes(native):
     q = torch.randn(1, 2, 40, 64, device="cuda")
     assert not native.attention_supported(q, q, 0, 40)                        # 40 is not a multiple of 32
