@@ -51,6 +51,14 @@ def main():
         e_lse = (lse.double() - lse_gold).abs().max().item()
         t_ref = timeit(lambda: F.scaled_dot_product_attention(q, k, v, attn_mask=keep, scale=scale))
         t_ours = timeit(lambda: nat.attention_forward(q, k, v, split, limit, scale))
+        tw = {}
+        for w in "1234":                          # forward waves per workgroup, forced
+            os.environ["PTOPS_ATTN_FWD_WAVES"] = w
+            o_w, _ = nat.attention_forward(q, k, v, split, limit, scale)
+            assert torch.equal(o_w, out)
+            tw[w] = timeit(lambda: nat.attention_forward(q, k, v, split, limit, scale)) * 1e3
+        os.environ.pop("PTOPS_ATTN_FWD_WAVES")
+        print(f"{name:18s} forward by waves per workgroup (1..4): " + "  ".join(f"{tw[w]:.1f}" for w in "1234") + f" us   auto {t_ours*1e3:.1f} us")
         # backward: library kernels vs aten::_efficient_attention_backward (what the step used before)
         from imgadapointr_amd.models import Transformer_utils as TU
         go = torch.randn(B, Nq, H, d, device="cuda")

@@ -808,10 +808,17 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
   a.scale_log2e = scale * 1.4426950408889634f;
   const int tiles = Nq / 32;
-  // waves per workgroup: the largest of {4,3,2} that divides the number of query tiles (576 -> 3)
-  int W = tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : (tiles % 2 == 0 ? 2 : 1));
-  if (W == 4 && (long long)(tiles / 4) * B * H < 3 * ptops::kNumCU) W = 2;  // short sequences: more, smaller workgroups
-  dim3 grid(tiles / W, B * H);
+  // Four waves per workgroup whenever there are four query tiles, a last workgroup with idle waves included
+  // (576 queries = 18 tiles -> 5 workgroups per head): the 4-wave instantiation fits 128 VGPRs, so four workgroups
+  // (16 waves) are resident per CU and e.g. all 960 workgroups of the 576-query training shape run in ONE round,
+  // where the 3-wave form (occupancy 3, 1152 workgroups on 1024 slots) needed a second, nearly empty one.
+  // Measured at B=32 (benchmarks/attention_bench.py, waves 1/2/3/4): 227/180/183/146 us (576x576 masked),
+  // 108/89/90/77 us (576x256), 58/47/58/43 us (256x256).
+  int W = tiles < 4 ? tiles : 4;
+  if (const char* force = getenv("PTOPS_ATTN_FWD_WAVES")) {                 // benchmarking knob
+    if (force[0] >= '1' && force[0] <= '4') W = force[0] - '0';
+  }
+  dim3 grid(ptops::ceil_div(tiles, W), B * H);
   switch (W) {
     case 4: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), 0, stream, a); break;
     case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(192), 0, stream, a); break;
