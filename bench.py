@@ -143,7 +143,14 @@ class AttentionProbe:
     def summary(self, steps):
         out = {"bound": "mfma", "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                "note": "fp32 v_mfma_f32_32x32x2_f32; executed MFMA FLOPs (forward 2 GEMMs, single-pass backward 5); "
-                       "PMC MFMA-busy fractions in profiles/round1/attention_pmc.json"}
+                       "pmc = separate rocprofv3 --pmc passes of the same launches (profiles/round1/attention_pmc_v2.json): "
+                       "matrix-pipe busy fraction and HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"}
+        pmc_file = os.path.join(ROOT, "profiles", "round1", "attention_pmc_v2.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                out["pmc"] = [{"kernel": k["kernel"], "workgroups": k["grid_threads"] // k["workgroup"],
+                               "launch_us": k["avg_duration_us_under_pmc"], "mfma_busy": k.get("mfma_utilisation"),
+                               "traffic": k["counters"].get("hbm_traffic_bytes")} for k in json.load(fh)["kernels"]]
         for kind, recs in self.rec.items():
             if not recs:
                 continue

@@ -2,8 +2,13 @@
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
-        --output-format csv -d /tmp/pmc -o attn -- python3 benchmarks/attention_bench.py
-    python3 benchmarks/pmc_attention.py /tmp/pmc/attn_counter_collection.csv /tmp/pmc/attn_kernel_trace.csv > profiles/roundN/attention_pmc.json
+        --output-format csv -d /tmp/pmc -o attn -- python3 benchmarks/attention_pmc_driver.py
+    (separate passes, same program, for --pmc FETCH_SIZE and --pmc WRITE_SIZE: -o fetch / -o write)
+    python3 benchmarks/pmc_attention.py /tmp/pmc/attn_counter_collection.csv /tmp/pmc/attn_kernel_trace.csv \
+        [/tmp/pmc/fetch_counter_collection.csv /tmp/pmc/write_counter_collection.csv] > profiles/roundN/attention_pmc_v2.json
+
+FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of a wide coalesced stream (MI355X_MICROARCH.md, HBM),
+so `hbm_traffic_bytes` = 2 x FETCH_SIZE + WRITE_SIZE.
 
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles (summed over SIMDs) in which the matrix pipe is busy; GRBM_GUI_ACTIVE counts
 active cycles summed over the 8 XCDs.  utilisation = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)."""
@@ -15,6 +20,7 @@ import sys
 
 def main():
     counters, trace = sys.argv[1], sys.argv[2]
+    extra = sys.argv[3:]
     dur = collections.defaultdict(list)
     with open(trace) as fh:
         for r in csv.DictReader(fh):
@@ -25,16 +31,19 @@ def main():
                 key = (n[n.index("attn_"):].split("(")[0], grid, wg)
                 dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
-    with open(counters) as fh:
-        for r in csv.DictReader(fh):
-            n = r["Kernel_Name"]
-            if "attn_" in n and "anonymous" in n:
-                key = (n[n.index("attn_"):].split("(")[0], r["Grid_Size"], r["Workgroup_Size"])
-                vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for path in [counters] + extra:
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                n = r["Kernel_Name"]
+                if "attn_" in n and "anonymous" in n:
+                    key = (n[n.index("attn_"):].split("(")[0], r["Grid_Size"], r["Workgroup_Size"])
+                    vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = []
     for key, cs in sorted(vals.items()):
         avg = {c: sum(v) / len(v) for c, v in cs.items()}
         d = dur.get(key, [])
+        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+            avg["hbm_traffic_bytes"] = 2 * 1024 * avg["FETCH_SIZE"] + 1024 * avg["WRITE_SIZE"]
         rec = {"kernel": key[0], "grid_threads": int(key[1]), "workgroup": int(key[2]), "launches": len(next(iter(cs.values()))),
                "avg_duration_us_under_pmc": round(sum(d) / len(d) / 1e3, 1) if d else None, "counters": avg}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
