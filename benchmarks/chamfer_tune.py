@@ -3,7 +3,6 @@ rounds in one process (cdna guide §5.4 rule 24).
 
 Needs a tuning build: make -C imgadapointr_amd/csrc clean && make -C imgadapointr_amd/csrc TUNING=1
 """
-import itertools
 import os
 import sys
 

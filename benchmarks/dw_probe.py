@@ -1,5 +1,5 @@
 """dW = dY^T X two ways (TunableOp on): g.t() @ x  vs  (x.t() @ g).t().contiguous()."""
-import torch, time
+import torch
 torch.cuda.tunable.enable(True); torch.cuda.tunable.tuning_enable(True)
 torch.cuda.tunable.set_max_tuning_duration(50); torch.cuda.tunable.set_max_tuning_iterations(50)
 def t(fn, n=30):

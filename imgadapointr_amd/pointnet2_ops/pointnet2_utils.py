@@ -5,7 +5,6 @@ utils/misc.py:10) and calls `furthest_point_sample` (models/base_blocks.py:550, 
 `gather_operation` (base_blocks.py:555, misc.py:38).  Same names, argument meaning and dtypes
 here, backed by libptops (imgadapointr_amd/csrc/fps.hip, gather.hip).
 """
-import torch
 from torch.autograd import Function
 
 from .. import _native

@@ -21,7 +21,6 @@ import torch
 import torch.nn as nn
 
 from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
-from ..utils import dist_utils
 from ..utils.AverageMeter import AverageMeter
 from ..utils.flat_ddp import FlatDDP
 from ..utils.graph_runner import GraphedForward

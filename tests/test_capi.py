@@ -1,5 +1,4 @@
 """The C-ABI library loads and exports every symbol include/ptops.h declares (no compute here)."""
-import ctypes
 import os
 import re
 
