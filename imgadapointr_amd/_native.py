@@ -54,7 +54,7 @@ def _declare(lib):
         "ptops_edge_select": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P, P, P, P]),
         "ptops_edge_scatter": (c_int, [P, P, P, P] + [c_int] * 5 + [P, P]),
         "ptops_edge_norm_forward": (c_int, [P] * 4 + [c_int] * 6 + [ctypes.c_float, ctypes.c_float, P, P, P]),
-        "ptops_edge_norm_backward_workspace_bytes": (c_size, [c_int] * 4),
+        "ptops_edge_norm_backward_workspace_bytes": (c_size, [c_int] * 6),
         "ptops_edge_norm_backward": (c_int, [P] * 10 + [c_int] * 6 + [ctypes.c_float] + [P] * 5),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
@@ -759,7 +759,7 @@ def edge_norm_backward(grad_out, ysel, ysum, P, R, idx, nsel, gamma, beta, mean_
         dP = torch.empty_like(P)
         dR = torch.empty_like(R)
         sums = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
-        ws = torch.empty((load().ptops_edge_norm_backward_workspace_bytes(B, C, Nq, groups) // 4 + 4,),
+        ws = torch.empty((load().ptops_edge_norm_backward_workspace_bytes(B, C, Nk, Nq, k, groups) // 4 + 4,),
                          dtype=torch.float32, device=dev)
         _call("ptops_edge_norm_backward", _ptr(grad_out), _ptr(ysel), _ptr(ysum), _ptr(P), _ptr(R), _ptr(idx), _ptr(nsel),
               _ptr(gamma), _ptr(beta), _ptr(mean_rstd), B, C, Nk, Nq, k, groups, ctypes.c_float(float(slope)), _ptr(dP),

@@ -302,6 +302,135 @@ __global__ __launch_bounds__(kTPB) void edge_scatter_dp_kernel(
   }
 }
 
+// ---- the same dP without the k float atomics per (channel, query): transpose the neighbour graph once ----------
+// edge_csr_kernel: for every key point n the queries q that list it (ascending), as rowptr [B][Nk+1] / col [B][Nq*k]
+// (uint16).  One workgroup per cloud; counting sort in LDS with integer atomics, rows sorted afterwards so that the
+// summation order of the gather - and with it dP - does not depend on atomic arrival order.
+constexpr int kCsrT = 1024;
+__global__ __launch_bounds__(kCsrT) void edge_csr_kernel(const int32_t* __restrict__ idx, int Nk, int Nq, int k,
+                                                         int32_t* __restrict__ rowptr, uint16_t* __restrict__ col) {
+  extern __shared__ __attribute__((aligned(16))) int csm[];  // cnt[Nk] | cur[Nk] | part[kCsrT] | col16[Nq*k] (uint16)
+  int* cnt = csm;
+  int* cur = cnt + Nk;
+  int* part = cur + Nk;
+  uint16_t* lcol = reinterpret_cast<uint16_t*>(part + kCsrT);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int E = Nq * k;
+  const int32_t* ib = idx + (size_t)b * E;
+  for (int n = tid; n < Nk; n += kCsrT) cnt[n] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += kCsrT) atomicAdd(&cnt[ib[e]], 1);
+  __syncthreads();
+  // exclusive scan of cnt: thread t owns the consecutive items [t*per, (t+1)*per)
+  const int per = (Nk + kCsrT - 1) / kCsrT;
+  int local = 0;
+  for (int i = 0; i < per; ++i) {
+    const int n = tid * per + i;
+    if (n < Nk) local += cnt[n];
+  }
+  part[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < kCsrT; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread totals
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - local;
+  int32_t* rp = rowptr + (size_t)b * (Nk + 1);
+  for (int i = 0; i < per; ++i) {
+    const int n = tid * per + i;
+    if (n < Nk) {
+      cur[n] = run;
+      rp[n] = run;
+      run += cnt[n];
+    }
+  }
+  if (tid == kCsrT - 1) rp[Nk] = part[tid];
+  __syncthreads();
+  for (int e = tid; e < E; e += kCsrT) {
+    const int pos = atomicAdd(&cur[ib[e]], 1);
+    lcol[pos] = (uint16_t)(e / k);
+  }
+  __syncthreads();
+  for (int n = tid; n < Nk; n += kCsrT) {  // insertion sort of each (short) row
+    const int end = cur[n], beg = end - cnt[n];
+    for (int i = beg + 1; i < end; ++i) {
+      const uint16_t v = lcol[i];
+      int j = i - 1;
+      while (j >= beg && lcol[j] > v) {
+        lcol[j + 1] = lcol[j];
+        --j;
+      }
+      lcol[j + 1] = v;
+    }
+  }
+  __syncthreads();
+  uint16_t* gc = col + (size_t)b * E;
+  for (int e = tid; e < E; e += kCsrT) gc[e] = lcol[e];
+}
+
+// dP[c, n] = cnt[n] (A + Bc P[c, n]) + Bc sum_{q in row n} R[c, q] + sum_{q : nsel[c, q] = n} S[c, q]
+// The dense term is a gather over the transposed graph from an LDS copy of Bc R[c, :]; only the selected-edge term
+// (one value per (channel, query) instead of k + 1) still goes through LDS float atomics.
+template <int CT>
+__global__ __launch_bounds__(kTPB) void edge_gather_dp_kernel(
+    const float* __restrict__ P, const float* __restrict__ R, const float* __restrict__ S,
+    const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ col, const int32_t* __restrict__ nsel,
+    const float* __restrict__ ab, int C, int G, int Nk, int Nq, int k, float* __restrict__ dP) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // rt[CT][Nq] | at[CT][Nk]
+  float* rt = tile;
+  float* at = tile + (size_t)CT * Nq;
+  const int b = blockIdx.y, c0 = blockIdx.x * CT;
+  const int cpg = C / G;
+  for (int t = threadIdx.x; t < CT * Nq; t += kTPB) {
+    const int ct = t / Nq, q = t - ct * Nq, c = c0 + ct;
+    rt[t] = c < C ? ab[2 * (b * G + c / cpg) + 1] * R[((size_t)b * C + c) * Nq + q] : 0.0f;
+  }
+  for (int t = threadIdx.x; t < CT * Nk; t += kTPB) at[t] = 0.0f;
+  __syncthreads();
+  for (int t = threadIdx.x; t < CT * Nq; t += kTPB) {
+    const int ct = t / Nq, q = t - ct * Nq, c = c0 + ct;
+    if (c < C) {
+      const size_t o = ((size_t)b * C + c) * Nq + q;
+      atomicAdd(&at[ct * Nk + nsel[o]], S[o]);
+    }
+  }
+  __syncthreads();
+  const int32_t* rp = rowptr + (size_t)b * (Nk + 1);
+  const uint16_t* gc = col + (size_t)b * Nq * k;
+  for (int n = threadIdx.x; n < Nk; n += kTPB) {
+    const int beg = rp[n], end = rp[n + 1];
+    float acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = 0.0f;
+    for (int e = beg; e < end; ++e) {
+      const int q = gc[e];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] += rt[ct * Nq + q];
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int c = c0 + ct;
+      if (c < C) {
+        const float A = ab[2 * (b * G + c / cpg)], Bc = ab[2 * (b * G + c / cpg) + 1];
+        const size_t o = ((size_t)b * C + c) * Nk + n;
+        dP[o] = (at[ct * Nk + n] + acc[ct]) + (float)(end - beg) * (A + Bc * P[o]);
+      }
+    }
+  }
+}
+
+// LDS bytes of the two kernels; the CSR path is used when both fit (else the atomic scatter above)
+size_t csr_lds_bytes(int Nk, int Nq, int k) { return sizeof(int) * (2 * (size_t)Nk + kCsrT) + sizeof(uint16_t) * (size_t)Nq * k + 16; }
+bool csr_eligible(int Nk, int Nq, int k) {
+  return Nq <= 65535 && csr_lds_bytes(Nk, Nq, k) <= 150 * 1024 && sizeof(float) * ((size_t)Nq + Nk) <= 64 * 1024;
+}
+size_t csr_workspace_bytes(int B, int Nk, int Nq, int k) {
+  const size_t rowptr = (sizeof(int32_t) * (size_t)B * (Nk + 1) + 15) / 16 * 16;
+  return rowptr + (sizeof(uint16_t) * (size_t)B * Nq * k + 15) / 16 * 16;
+}
+
 }  // namespace
 
 PTOPS_API int ptops_edge_select_blocks(int Nq) { return ptops::ceil_div(Nq, kTPB); }
@@ -357,9 +486,13 @@ PTOPS_API int ptops_edge_norm_forward(const float* ysel, const float* partial, c
   return ptops::check_launch("edge_norm_forward");
 }
 
-PTOPS_API size_t ptops_edge_norm_backward_workspace_bytes(int B, int C, int Nq, int groups) {
-  if (B <= 0 || C <= 0 || Nq <= 0 || groups <= 0) return 0;
-  return sizeof(float) * ((size_t)B * C * Nq + 2 * (size_t)B * groups + 4);
+static size_t edge_bwd_float_ws(int B, int C, int Nq, int groups) {
+  return ((size_t)B * C * Nq + 2 * (size_t)B * groups + 4 + 3) / 4 * 4;   // floats, 16-byte multiple
+}
+
+PTOPS_API size_t ptops_edge_norm_backward_workspace_bytes(int B, int C, int Nk, int Nq, int k, int groups) {
+  if (B <= 0 || C <= 0 || Nk <= 0 || Nq <= 0 || k <= 0 || groups <= 0) return 0;
+  return sizeof(float) * edge_bwd_float_ws(B, C, Nq, groups) + (csr_eligible(Nk, Nq, k) ? csr_workspace_bytes(B, Nk, Nq, k) : 0);
 }
 
 PTOPS_API int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const float* ysum, const float* P,
@@ -385,6 +518,26 @@ PTOPS_API int ptops_edge_norm_backward(const float* grad_out, const float* ysel,
                      mean_rstd, B * groups, C, groups, M, ab);
   hipLaunchKernelGGL(edge_bwd_apply_kernel, dim3(ptops::ceil_div(Nq, 256), B * C), dim3(256), 0, stream, grad_out, ysel,
                      ysum, gamma, beta, mean_rstd, ab, C, groups, Nq, k, slope, S, dR);
+  if (csr_eligible(Nk, Nq, k)) {
+    int32_t* rowptr = reinterpret_cast<int32_t*>((float*)workspace + edge_bwd_float_ws(B, C, Nq, groups));
+    uint16_t* col = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(rowptr) +
+                                                (sizeof(int32_t) * (size_t)B * (Nk + 1) + 15) / 16 * 16);
+    const size_t csr_lds = csr_lds_bytes(Nk, Nq, k);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_csr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)csr_lds);
+    hipLaunchKernelGGL(edge_csr_kernel, dim3(B), dim3(kCsrT), csr_lds, stream, idx, Nk, Nq, k, rowptr, col);
+    int CT = 8;
+    while (CT > 1 && ((long long)B * ptops::ceil_div(C, CT) < 512 || (size_t)CT * (Nq + Nk) * 4 > 64 * 1024)) CT >>= 1;
+    dim3 grid(ptops::ceil_div(C, CT), B);
+    const size_t lds = (size_t)CT * ((size_t)Nq + Nk) * sizeof(float);
+    switch (CT) {
+      case 8: hipLaunchKernelGGL(edge_gather_dp_kernel<8>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+      case 4: hipLaunchKernelGGL(edge_gather_dp_kernel<4>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+      case 2: hipLaunchKernelGGL(edge_gather_dp_kernel<2>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+      default: hipLaunchKernelGGL(edge_gather_dp_kernel<1>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;
+    }
+    return ptops::check_launch("edge_norm_backward");
+  }
   int CT = 8;
   while (CT > 1 && ((long long)B * ptops::ceil_div(C, CT) < 512 || (size_t)(CT + 1) * Nk * 4 > 64 * 1024)) CT >>= 1;
   dim3 grid(ptops::ceil_div(C, CT), B);

@@ -264,12 +264,13 @@ int ptops_edge_scatter(const float* dense, const float* sel, const int32_t* idx,
  *   mean_rstd [B,groups,2], and out = LeakyReLU(gamma * (ysel - mean) * rstd + beta)  [B,C,Nq].
  * ptops_edge_norm_backward: from grad_out [B,C,Nq] the gradients dP [B,C,Nk], dR [B,C,Nq] of the two
  *   conv halves and sums [B,C,2] = {sum_q dz, sum_q dz*yhat} (dbeta / dgamma are their sums over B);
- *   workspace of ptops_edge_norm_backward_workspace_bytes(B, C, Nq, groups) bytes.  Deterministic
- *   except for the order of the LDS float adds of the scatter (as ptops_edge_scatter). */
+ *   workspace of ptops_edge_norm_backward_workspace_bytes(B, C, Nk, Nq, k, groups) bytes (16-byte aligned).
+ *   The neighbour graph is transposed once per call (counting sort, rows ordered) and dP gathered from it;
+ *   only the selected-edge term (one value per channel and query) goes through LDS float adds. */
 int ptops_edge_norm_forward(const float* ysel, const float* partial, const float* gamma,
                             const float* beta, int B, int C, int Nq, int nblk, int groups, int k,
                             float eps, float slope, float* out, float* mean_rstd, void* stream);
-size_t ptops_edge_norm_backward_workspace_bytes(int B, int C, int Nq, int groups);
+size_t ptops_edge_norm_backward_workspace_bytes(int B, int C, int Nk, int Nq, int k, int groups);
 int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const float* ysum,
                              const float* P, const float* R, const int32_t* idx, const int32_t* nsel,
                              const float* gamma, const float* beta, const float* mean_rstd, int B, int C,
