@@ -17,6 +17,7 @@
 //  * points with |p|^2 <= 1e-3 (zero padding) get min-distance -2 at load time, which the
 //    update min(d, -2) keeps forever and the arg-max (start value -1) can never pick.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ptops_common.h"
 
@@ -161,10 +162,23 @@ PTOPS_API int ptops_furthest_point_sample(const float* xyz, int B, int N, int np
   if (B == 0 || npoint == 0) return PTOPS_OK;
   PTOPS_REQUIRE(xyz && idx, "furthest_point_sample: null pointer");
   PTOPS_REQUIRE(N <= 16384, "furthest_point_sample: N=%d exceeds the in-register limit 16384", N);
+#ifdef PTOPS_TUNING  // benchmarks/fps_tune.py: PTOPS_TUNE_FPS = threads * 100 + points per lane
+  if (const char* t = getenv("PTOPS_TUNE_FPS")) {
+    const int code = atoi(t);
+    if (code == 25608 && N <= 2048) return launch<256, 8>(xyz, B, N, npoint, idx, stream);
+    if (code == 51204 && N <= 2048) return launch<512, 4>(xyz, B, N, npoint, idx, stream);
+    if (code == 102402 && N <= 2048) return launch<1024, 2>(xyz, B, N, npoint, idx, stream);
+    if (code == 12816 && N <= 2048) return launch<128, 16>(xyz, B, N, npoint, idx, stream);
+    if (code == 12804 && N <= 512) return launch<128, 4>(xyz, B, N, npoint, idx, stream);
+    if (code == 6408 && N <= 512) return launch<64, 8>(xyz, B, N, npoint, idx, stream);
+    if (code == 51201 && N <= 512) return launch<512, 1>(xyz, B, N, npoint, idx, stream);
+    if (code == 25602 && N <= 512) return launch<256, 2>(xyz, B, N, npoint, idx, stream);
+  }
+#endif
   if (N <= 256) return launch<256, 1>(xyz, B, N, npoint, idx, stream);
   if (N <= 512) return launch<256, 2>(xyz, B, N, npoint, idx, stream);
   if (N <= 1024) return launch<512, 2>(xyz, B, N, npoint, idx, stream);
-  if (N <= 2048) return launch<512, 4>(xyz, B, N, npoint, idx, stream);
+  if (N <= 2048) return launch<256, 8>(xyz, B, N, npoint, idx, stream);   // 330 vs 346 us for 512 picks (fps_tune.py)
   if (N <= 4096) return launch<1024, 4>(xyz, B, N, npoint, idx, stream);
   if (N <= 8192) return launch<1024, 8>(xyz, B, N, npoint, idx, stream);
   return launch<1024, 16>(xyz, B, N, npoint, idx, stream);
