@@ -1,5 +1,5 @@
-"""FPS launch shapes (threads per cloud x points per lane) at the two training sizes, B = 32 (needs the library built
-with -DPTOPS_TUNING, the Makefile default)."""
+"""FPS launch shapes (threads per cloud x points per lane) at the two training sizes, B = 32 (needs the tuning build of the
+library: `make -C imgadapointr_amd/csrc clean && make -C imgadapointr_amd/csrc TUNING=1`; rebuild without TUNING afterwards)."""
 import os
 import sys
 
