@@ -89,13 +89,26 @@ FAST_BIAS_GRAD = True
 _column_sums = {}
 
 
+def _layout_key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.storage_offset())
+
+
 def _offer_column_sums(t, sums):
-    _column_sums[(t.data_ptr(), tuple(t.shape))] = (t, sums)   # holding `t` keeps the address from being reused
+    # holding `t` keeps the address from being reused; its version counter detects an in-place write after the offer
+    _column_sums[_layout_key(t)] = (t, sums, t._version)
 
 
 def _take_column_sums(t):
-    hit = _column_sums.pop((t.data_ptr(), tuple(t.shape)), None)
-    return None if hit is None else hit[1]     # the table keeps the producer's tensor alive: same address = same data
+    """Column sums offered for exactly this tensor: same storage address, shape, strides and offset, not written to
+    since the offer.  Anything else (e.g. a transposed view of a square gradient: same address and shape, other
+    strides) returns None and the caller runs its own column-sum kernel."""
+    hit = _column_sums.pop(_layout_key(t), None)
+    if hit is None:
+        return None
+    src, sums, version = hit
+    if src.dtype != t.dtype or src._version != version:      # views share the version counter of their base
+        return None
+    return sums
 
 
 def _clear_column_sums():

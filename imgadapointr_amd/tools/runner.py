@@ -157,8 +157,12 @@ def run_net(args, config, train_writer=None, val_writer=None):
                 acc = loss_acc.clone()
                 if args.distributed:
                     torch.distributed.all_reduce(acc)  # one packed collective per log line
+                    if step.ddp is not None:
+                        step.ddp.check_late_gradients()   # same error on every rank instead of a hang (flat_ddp.py)
                 s, d, c = acc.tolist()
-                losses.update([s / c * 1000, d / c * 1000])
+                # window mean, weighted by the iterations it covers: losses.avg() is the per-iteration epoch mean
+                # of the reference (tools/runner.py:221-222), losses.val() the mean since the last log line
+                losses.update([s / c * 1000, d / c * 1000], n=max(1, round(c / max(1, args.world_size if args.distributed else 1))))
                 loss_acc.zero_()
                 n_itr = epoch * n_batches + idx
                 if train_writer is not None:
@@ -202,6 +206,8 @@ def _synset_names():
 
 def validate(base_model, test_dataloader, epoch, ChamferDisL1, ChamferDisL2, val_writer, args, config, logger=None):
     print_log(f'[VALIDATION] Start validating epoch {epoch}', logger=logger)
+    if isinstance(base_model, FlatDDP):
+        base_model.sync_buffers()      # rank 0's BatchNorm running statistics on every rank (DDP: broadcast_buffers)
     base_model.eval()
     device = next(base_model.parameters()).device
     test_losses = AverageMeter(['SparseLossL1', 'SparseLossL2', 'DenseLossL1', 'DenseLossL2'])

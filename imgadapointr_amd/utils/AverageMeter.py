@@ -1,7 +1,7 @@
 """Running last-value / mean trackers for one or several named quantities.
 
 Call surface of utils/AverageMeter.py of the reference: AverageMeter(items=None) with
-update(value | list), val(idx=None), count(idx=None), avg(idx=None), reset().
+update(value | list[, n]), val(idx=None), count(idx=None), avg(idx=None), reset().
 """
 import numpy as np
 
@@ -15,12 +15,14 @@ class AverageMeter(object):
     def reset(self):
         self._stats = np.zeros((3, self.n_items), dtype=np.float64)  # rows: last value, sum, count
 
-    def update(self, values):
+    def update(self, values, n=1):
+        """`n` > 1: `values` are means over n samples (the runner reads its on-device loss accumulator once per log
+        line); avg() stays the per-sample mean the reference computes with one update per iteration."""
         vals = values if isinstance(values, list) else [values]
         for i, v in enumerate(vals):
             self._stats[0, i] = v
-            self._stats[1, i] += v
-            self._stats[2, i] += 1
+            self._stats[1, i] += v * n
+            self._stats[2, i] += n
 
     def _select(self, row, idx, as_int=False):
         conv = (lambda x: int(x)) if as_int else (lambda x: float(x))

@@ -17,7 +17,16 @@ Replaces the reference's `nn.parallel.DistributedDataParallel(..., find_unused_p
     bucket whose hooks did not all fire (rare control-flow change; missing gradients count as zero)
     and divides by world size;
   * `set_sync(False)` turns the averaging off for a backward (gradient accumulation over several
-    micro-batches: only the last one is averaged, as with DDP's `no_sync`).
+    micro-batches: only the last one is averaged, as with DDP's `no_sync`);
+  * the participating set is agreed on by ALL ranks (one bitmap all-reduce on the first step), so every rank
+    builds the same buckets even if a data-dependent branch skipped a parameter on one of them;
+  * a parameter outside the buckets that receives a gradient later is never averaged by an extra collective
+    (a collective only some ranks enter hangs the job): its gradient is dropped on that rank, so the parameter
+    stays identical everywhere, and `check_late_gradients()` — a collective the runner calls at its log lines —
+    raises the same error on every rank; `rediscover()` re-learns the set on the next step;
+  * buffers (BatchNorm running statistics) are broadcast from rank 0 at wrap time and by `sync_buffers()`, which
+    the runner calls before validation: DDP's `broadcast_buffers=True` makes rank 0's statistics the ones every
+    rank evaluates with; here they are synchronised where they are read instead of once per forward.
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +48,7 @@ class FlatDDP(nn.Module):
         self._hooks = []
         self._discovered = False
         self._sync = True
+        self._late = set()
         # RCCL averages inside the collective; gloo (CPU tests) only sums, so divide afterwards there
         self._avg_in_collective = (self._collective and dist.get_backend(process_group) == "nccl")
         # identical start: rank 0's parameters and buffers everywhere (as DDP does at wrap time)
@@ -120,12 +130,22 @@ class FlatDDP(nn.Module):
             b["handle"] = None
             b["packed"] = False
 
+    def _agree_on_used(self, trainable):
+        """First step: the union over ranks of the parameters that received a gradient."""
+        used = [p.grad is not None for p in trainable]
+        if self._collective and trainable:
+            dev = trainable[0].device
+            bitmap = torch.tensor(used, dtype=torch.int32).to(dev)
+            dist.all_reduce(bitmap, op=dist.ReduceOp.MAX, group=self.process_group)
+            used = [bool(v) for v in bitmap.tolist()]
+        return [p for p, u in zip(trainable, used) if u]
+
     def finalize(self):
         """Call once after the (last) backward of a step: completes the gradient averaging."""
         if not self._discovered:
-            # First step: learn which parameters take part, average them without overlap.
-            used = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
-            self._build_buckets(used)
+            # First step: learn which parameters take part (rank-consistently), average them without overlap.
+            trainable = [p for p in self.module.parameters() if p.requires_grad]
+            self._build_buckets(self._agree_on_used(trainable))
             self._discovered = True
             for b in self._buckets:
                 self._launch(b, async_op=False)
@@ -141,11 +161,43 @@ class FlatDDP(nn.Module):
                     b["handle"].wait()
                 if not self._avg_in_collective:
                     b["flat"].div_(self.world_size)
-            # a parameter outside the buckets that suddenly received a gradient
-            for p in self.module.parameters():
+            # A parameter outside the buckets that suddenly received a gradient: no collective here (other ranks may
+            # not have it and would never enter one).  Dropping the local gradient keeps the parameter identical on
+            # every rank; check_late_gradients() reports it on all of them.
+            for n, p in self.module.named_parameters():
                 if p.requires_grad and p.grad is not None and p not in self._param_bucket:
-                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.process_group)
-                    p.grad.div_(self.world_size)
+                    p.grad = None
+                    self._late.add(n)
+
+    def check_late_gradients(self):
+        """Collective (every rank must call it at the same point, e.g. at a log line).  Raises on EVERY rank if any
+        rank met a gradient for a parameter that the first step left out of the buckets."""
+        flag = torch.tensor([1 if self._late else 0], dtype=torch.int32)
+        if self._collective:
+            flag = flag.to(next(self.module.parameters()).device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.process_group)
+        if int(flag.item()):
+            names = sorted(self._late)
+            raise RuntimeError(
+                "FlatDDP: parameters outside the gradient buckets received a gradient after the first step "
+                f"(on this rank: {names if names else 'none, another rank did'}); their updates were skipped. "
+                "Call rediscover() to re-learn the participating set on the next step.")
+
+    def rediscover(self):
+        """Forget the buckets: the next finalize() learns the participating parameters again (on every rank)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._buckets, self._param_bucket = None, {}
+        self._discovered = False
+        self._late = set()
+        self.zero_grad()
+
+    def sync_buffers(self):
+        """Rank 0's buffers (BatchNorm running statistics, counters) everywhere.  Collective."""
+        if self._collective:
+            for t in self.module.buffers():
+                dist.broadcast(t.data, src=0, group=self.process_group)
 
     def unused_parameter_names(self):
         """Names of the trainable parameters that received no gradient on the first step."""

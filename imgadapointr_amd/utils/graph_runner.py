@@ -4,11 +4,25 @@ The reference validates and tests with batch size 1 (tools/runner.py:401-450, 48
 with microseconds of work each, so the forward is bound by launch latency, not by the GPU (7.7 ms eager vs 2.8 ms
 replayed on an MI355X at bs = 1; 7.8 vs 4.6 ms at bs = 8).  `GraphedForward` captures `model(*inputs)` once per input
 signature under `torch.no_grad()` in eval mode and replays it; the library's ctypes launches go to the capturing stream
-like any other kernel.  Anything that cannot be captured (a host synchronisation inside the forward, e.g. the fallback
-branch of the normal estimation) disables the graph for that model and the call runs eagerly — results are identical
-either way.
+like any other kernel.
+
+Safety rules (a graph that silently replays the wrong thing is worse than no graph):
+  * capture and replay run under `torch.cuda.device(<device of the inputs>)`, so a model on a GPU that is not the
+    current device is captured on ITS stream (otherwise the kernels would run eagerly there while an empty graph is
+    recorded on the current device and every later replay would return the first call's outputs);
+  * all inputs must live on one device, which is part of the cache key;
+  * after capture the graph is replayed once and compared with the eager warm-up outputs; a mismatch (or an empty
+    graph) disables graphing for this model and says why;
+  * only capture failures (RuntimeError / TypeError from the stream capture) fall back to eager, and the reason is
+    logged; an out-of-memory error is re-raised;
+  * at most `max_graphs` captured signatures are kept (least recently used is dropped together with its memory pool).
 """
+import logging
+from collections import OrderedDict
+
 import torch
+
+_log = logging.getLogger(__name__)
 
 
 def _flatten(out):
@@ -20,52 +34,105 @@ def _flatten(out):
     return None, None
 
 
+def input_device(inputs):
+    """The one CUDA device all `inputs` live on, or None (CPU tensors, non-tensors, mixed devices)."""
+    dev = None
+    for t in inputs:
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            return None
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            return None
+    return dev
+
+
+def signature(inputs):
+    """Cache key of a call: shapes, dtypes and the device of the inputs."""
+    return tuple((tuple(t.shape), t.dtype, t.device.type, t.device.index) for t in inputs)
+
+
 class GraphedForward:
-    def __init__(self, model, warmup=2, enabled=True):
+    def __init__(self, model, warmup=2, enabled=True, max_graphs=4, verify=True, rtol=1e-4, atol=1e-5):
         self.model = model
-        self.warmup = warmup
+        self.warmup = max(1, warmup)
         self.enabled = enabled
-        self._cache = {}
+        self.max_graphs = max(1, max_graphs)
+        self.verify = verify
+        self.rtol, self.atol = rtol, atol
+        self._cache = OrderedDict()
         self.replays = 0
+        self.disabled_reason = None
 
     def _eligible(self, inputs):
         return (self.enabled and not torch.is_grad_enabled() and not self.model.training and len(inputs) > 0
-                and all(isinstance(t, torch.Tensor) and t.is_cuda for t in inputs))
+                and input_device(inputs) is not None)
 
-    def _capture(self, inputs):
+    def _disable(self, reason):
+        self.enabled = False
+        self.disabled_reason = reason
+        self._cache.clear()
+        _log.warning("GraphedForward: falling back to eager forwards (%s)", reason)
+
+    def _capture(self, inputs, device):
+        """Runs on `device` (the caller holds the device guard).  -> cache entry or None (graphing disabled)."""
         static_in = [t.clone() for t in inputs]
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
                 for _ in range(self.warmup):
-                    self.model(*static_in)
-            torch.cuda.current_stream().wait_stream(side)
+                    eager = self.model(*static_in)
+            torch.cuda.current_stream(device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.model(*static_in)
-            flat, rebuild = _flatten(out)
-            if flat is None:
-                raise TypeError("the forward must return a tensor or a flat tuple / list of tensors")
-            return static_in, graph, flat, rebuild
-        except Exception:  # not capturable: stay eager for this model
-            torch.cuda.synchronize()
-            self.enabled = False
+        except torch.cuda.OutOfMemoryError:
+            raise
+        except (RuntimeError, TypeError) as exc:      # a host sync / unsupported call inside the forward
+            torch.cuda.synchronize(device)
+            self._disable(f"capture failed: {type(exc).__name__}: {exc}")
             return None
+        flat, rebuild = _flatten(out)
+        if flat is None:
+            self._disable("the forward must return a tensor or a flat tuple / list of tensors")
+            return None
+        if any(t.device != device for t in flat):
+            self._disable(f"outputs are not on the inputs' device {device}")
+            return None
+        if self.verify:
+            eager_flat, _ = _flatten(eager)
+            for t in flat:                            # a graph that recorded nothing leaves these untouched
+                t.fill_(float("nan")) if t.is_floating_point() else t.zero_()
+            graph.replay()
+            torch.cuda.synchronize(device)
+            ok = eager_flat is not None and len(eager_flat) == len(flat) and all(
+                (torch.allclose(a, b, rtol=self.rtol, atol=self.atol) if a.is_floating_point() else torch.equal(a, b))
+                for a, b in zip(flat, eager_flat))
+            if not ok:
+                self._disable("a replay did not reproduce the eager forward")
+                return None
+        return static_in, graph, flat, rebuild
 
     def __call__(self, *inputs):
         if not self._eligible(inputs):
             return self.model(*inputs)
-        key = tuple((tuple(t.shape), t.dtype, t.device.index) for t in inputs)
-        entry = self._cache.get(key)
-        if entry is None:
-            entry = self._capture(inputs)
+        device = input_device(inputs)
+        key = signature(inputs)
+        with torch.cuda.device(device):
+            entry = self._cache.get(key)
             if entry is None:
-                return self.model(*inputs)
-            self._cache[key] = entry
-        static_in, graph, flat, rebuild = entry
-        for s, t in zip(static_in, inputs):
-            s.copy_(t)
-        graph.replay()
-        self.replays += 1
-        return rebuild([t.clone() for t in flat])     # the static outputs are overwritten by the next replay
+                entry = self._capture(inputs, device)
+                if entry is None:
+                    return self.model(*inputs)
+                self._cache[key] = entry
+                while len(self._cache) > self.max_graphs:
+                    self._cache.popitem(last=False)       # drops the graph and its private pool
+            else:
+                self._cache.move_to_end(key)
+            static_in, graph, flat, rebuild = entry
+            for s, t in zip(static_in, inputs):
+                s.copy_(t)
+            graph.replay()
+            self.replays += 1
+            return rebuild([t.clone() for t in flat])     # the static outputs are overwritten by the next replay

@@ -44,6 +44,8 @@ def main():
     if args.launcher == 'none':
         args.distributed = False
         args.world_size = 1
+        if args.use_gpu:                      # `--launcher none --local_rank N` runs on GPU N: make it the current device
+            torch.cuda.set_device(args.local_rank)
     else:
         args.distributed = True
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

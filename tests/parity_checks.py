@@ -216,6 +216,17 @@ def check_train_forward_and_loss(device, tol=2e-4):
     assert abs(total - mt["grad_sq_norm_total"]) <= 5e-3 * mt["grad_sq_norm_total"], (total, mt["grad_sq_norm_total"])
     for n, v in mt["grad_sq_norm_sample"].items():
         assert abs(gsq[n] - v) <= 2e-2 * max(v, 1e-12) + 1e-12, (n, gsq[n], v)
+    # element-wise: whole gradient vectors of bias / norm parameters against the reference (make_golden_grads.py).
+    # A squared norm cannot see a sign flip or a permutation (e.g. a bias gradient taken from column sums that belong
+    # to another tensor); the direction can.  Same ~1 % arg-max-flip noise as above, hence 3 % of the vector's norm.
+    gv = load("adapointr_grads.npz")
+    named = dict(model.named_parameters())
+    for n in gv.files:
+        want = gv[n].astype(np.float64)
+        got = named[n].grad.detach().double().cpu().numpy()
+        assert got.shape == want.shape, n
+        err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+        assert err < 3e-2, (n, err)
     return l_den.item(), l_rec.item()
 
 

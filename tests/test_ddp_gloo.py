@@ -155,3 +155,78 @@ def _model_worker(rank, world, port, out):
 @pytest.mark.timeout(600)
 def test_two_rank_adapointr_train_step(tmp_path):
     mp.spawn(_model_worker, args=(2, 29612, str(tmp_path / "x")), nprocs=2, join=True)
+
+
+class Branchy(nn.Module):
+    """`side` takes part only when asked to: a data-dependent branch that differs between ranks / steps."""
+
+    def __init__(self):
+        super().__init__()
+        self.main = nn.Linear(8, 4)
+        self.side = nn.Linear(8, 4)
+        self.bn = nn.BatchNorm1d(4)
+
+    def forward(self, x, use_side):
+        y = self.bn(self.main(x))
+        return y + self.side(x) if use_side else y
+
+
+def _consistency_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from imgadapointr_amd.utils.flat_ddp import FlatDDP
+    _init(rank, world, port)
+    torch.manual_seed(3)
+    # (a) first step: only rank 1 takes the branch -> BOTH ranks must put `side` into their buckets
+    net = Branchy()
+    ddp = FlatDDP(net, bucket_mb=0.0001)
+    ddp.zero_grad()
+    x = torch.randn(6, 8)
+    ddp(x, use_side=(rank == 1)).pow(2).mean().backward()
+    ddp.finalize()
+    assert ddp.unused_parameter_names() == [], ddp.unused_parameter_names()
+    g = net.side.weight.grad.clone()
+    gs = [torch.empty_like(g) for _ in range(world)]
+    dist.all_gather(gs, g)
+    assert torch.equal(gs[0], gs[1]) and gs[0].abs().sum() > 0      # rank 1's gradient / 2 on both ranks
+    ddp.zero_grad()
+    ddp(x, use_side=False).pow(2).mean().backward()                  # a hook that never fires: zeros, no hang
+    ddp.finalize()
+    assert net.side.weight.grad.abs().sum() == 0
+    ddp.check_late_gradients()                                       # nothing late
+
+    # (b) `side` unused on step 1, used later on rank 0 only: dropped locally, reported on BOTH ranks, no hang
+    net2 = Branchy()
+    ddp2 = FlatDDP(net2, bucket_mb=0.0001)
+    ddp2.zero_grad()
+    ddp2(x, use_side=False).pow(2).mean().backward()
+    ddp2.finalize()
+    assert sorted(ddp2.unused_parameter_names()) == ["side.bias", "side.weight"]
+    ddp2.zero_grad()
+    ddp2(x, use_side=(rank == 0)).pow(2).mean().backward()
+    ddp2.finalize()
+    assert net2.side.weight.grad is None                             # never applied un-averaged
+    with pytest.raises(RuntimeError, match="after the first step"):
+        ddp2.check_late_gradients()
+    ddp2.rediscover()
+    ddp2(x, use_side=(rank == 0)).pow(2).mean().backward()
+    ddp2.finalize()
+    assert ddp2.unused_parameter_names() == []
+    ddp2.check_late_gradients()
+
+    # (c) BatchNorm running statistics drift per rank (different data), sync_buffers makes them rank 0's
+    net.train()
+    ddp.zero_grad()
+    ddp(torch.randn(6, 8) * (1 + rank), use_side=False).sum().backward()
+    ddp.finalize()
+    rm = [torch.empty_like(net.bn.running_mean) for _ in range(world)]
+    dist.all_gather(rm, net.bn.running_mean.clone())
+    assert not torch.equal(rm[0], rm[1])
+    ddp.sync_buffers()
+    dist.all_gather(rm, net.bn.running_mean.clone())
+    assert torch.equal(rm[0], rm[1])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_ddp_rank_consistency(tmp_path):
+    mp.spawn(_consistency_worker, args=(2, 29614, str(tmp_path / "x")), nprocs=2, join=True)

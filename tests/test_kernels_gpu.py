@@ -383,6 +383,42 @@ def test_packed_self_attention_and_linear_bias_grad(native):
     assert torch.equal(native.colsum(g3), native.colsum(g3))
 
 
+def test_bias_gradient_handoff_ignores_other_layouts(native):
+    """Column sums a producer kernel offers for a gradient tensor are taken only for that very layout.
+    A transposed view of a square gradient has the same address and shape but other strides; an in-place write after
+    the offer changes the data: both must fall back to the column-sum kernel."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(9)
+    M = C = 2304                                           # square, >= 2048 rows: the _LinearFn path
+    lin = TU.Linear(C, C).cuda()
+    x = torch.randn(M, C, device="cuda", requires_grad=True)
+    g = torch.randn(M, C, device="cuda")
+    wrong = torch.full((C,), 123.0, device="cuda")         # what a stale hand-off would deliver
+    want = g.t().double().sum(0)
+
+    def bias_grad(grad_out):
+        lin.bias.grad = None
+        y = lin(x)
+        assert type(y.grad_fn).__name__.startswith("_LinearFn")
+        y.backward(grad_out)
+        return lin.bias.grad.double()
+
+    TU._clear_column_sums()
+    TU._offer_column_sums(g, wrong)
+    got = bias_grad(g.t())                                 # same storage, same shape, transposed strides
+    assert (got - want).abs().max().item() < 2e-3, "took column sums that belong to another layout"
+    TU._clear_column_sums()
+    TU._offer_column_sums(g, wrong)
+    g.mul_(1.0)                                            # version bump after the offer
+    got = bias_grad(g)
+    assert (got - g.double().sum(0)).abs().max().item() < 2e-3, "took column sums of a tensor written to since"
+    TU._clear_column_sums()
+    sums = native.colsum(g)
+    TU._offer_column_sums(g, sums)
+    assert torch.equal(bias_grad(g), sums.double())        # the intended hit still works
+    assert not TU._column_sums                             # and is consumed
+
+
 @pytest.mark.parametrize("B,N", [(3, 512), (2, 2048)])
 def test_fused_edge_conv_matches_literal_chain(native, B, N):
     """DGCNN grouper: fused gather/statistics/select kernels vs the reference's literal

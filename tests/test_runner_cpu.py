@@ -121,3 +121,38 @@ def test_parser_paths(tmp_path, monkeypatch):
     assert args.log_name == 'AdaPoinTr' and os.path.isdir(args.experiment_path)
     with pytest.raises(ValueError):
         parser.get_args(['--test', '--resume'])
+
+
+def test_graphed_forward_device_rules():
+    """GraphedForward keys its graphs by the inputs' device and never graphs CPU or mixed-device calls
+    (utils/graph_runner.py; the capture / replay paths themselves are GPU tests)."""
+    from imgadapointr_amd.utils.graph_runner import GraphedForward, input_device, signature
+
+    class M(torch.nn.Module):
+        def forward(self, x):
+            return x + 1
+
+    a = torch.zeros(2, 3)
+    assert input_device([a]) is None and input_device([a, "x"]) is None and input_device([]) is None
+    m0, m1 = torch.empty(2, 3, device="meta"), torch.empty(2, 3, device="meta", dtype=torch.float16)
+    assert signature([m0]) != signature([m1])
+    assert signature([m0])[0][2:] == ("meta", None) or signature([m0])[0][2] == "meta"   # device type and index are in the key
+    gf = GraphedForward(M().eval())
+    with torch.no_grad():
+        assert torch.equal(gf(a), a + 1)                           # CPU input: plain eager call
+    assert gf.replays == 0 and gf.enabled and not gf._cache
+
+
+def test_average_meter_weighted_update_is_the_per_iteration_mean():
+    """The runner reads its on-device loss accumulator once per log line and feeds the window mean with the window's
+    iteration count: avg() must equal the reference's one-update-per-iteration mean (utils/AverageMeter.py)."""
+    from imgadapointr_amd.utils.AverageMeter import AverageMeter
+    vals = [float(v) for v in range(1, 12)]                 # 11 iterations, windows of 1, 5 and 5 (log_every = 5)
+    per_iter, windowed = AverageMeter(['a']), AverageMeter(['a'])
+    for v in vals:
+        per_iter.update([v])
+    for lo, hi in ((0, 1), (1, 6), (6, 11)):
+        w = vals[lo:hi]
+        windowed.update([sum(w) / len(w)], n=len(w))
+    assert abs(windowed.avg(0) - per_iter.avg(0)) < 1e-12
+    assert windowed.count(0) == 11 and windowed.val(0) == sum(vals[6:]) / 5

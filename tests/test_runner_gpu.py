@@ -72,6 +72,50 @@ def test_graphed_forward_matches_eager(native):
 
 
 @pytest.mark.gpu
+def test_graphed_forward_guards(native):
+    """LRU cap on captured signatures, eager fallback with a stated reason when the forward cannot be captured,
+    and the replay-vs-eager check that rejects a graph which does not reproduce the forward."""
+    from imgadapointr_amd.utils.graph_runner import GraphedForward
+
+    class Scale(torch.nn.Module):
+        def forward(self, x):
+            return x * 2.0 + 1.0
+
+    gf = GraphedForward(Scale().cuda().eval(), max_graphs=1)
+    with torch.no_grad():
+        for n in (8, 16, 8, 16):                                  # two signatures, one slot: re-captured, never stale
+            x = torch.rand(n, 3, device="cuda")
+            assert torch.equal(gf(x), x * 2.0 + 1.0)
+            assert len(gf._cache) == 1
+    assert gf.enabled and gf.replays == 4
+
+    class HostSync(torch.nn.Module):
+        def forward(self, x):
+            return x * float(x.sum().item())                      # device-to-host read: not capturable
+
+    gs = GraphedForward(HostSync().cuda().eval())
+    with torch.no_grad():
+        x = torch.rand(4, 3, device="cuda")
+        assert torch.allclose(gs(x), x * x.sum())
+        assert not gs.enabled and "capture failed" in gs.disabled_reason
+        assert torch.allclose(gs(x), x * x.sum())                 # stays eager afterwards
+
+    class Stateful(torch.nn.Module):                              # every call returns something else: a replay cannot
+        def __init__(self):                                       # reproduce the eager warm-up -> graphing is refused
+            super().__init__()
+            self.register_buffer("calls", torch.zeros(()))
+
+        def forward(self, x):
+            self.calls += 1
+            return x + self.calls
+
+    gd = GraphedForward(Stateful().cuda().eval())
+    with torch.no_grad():
+        gd(torch.zeros(4, device="cuda"))
+    assert not gd.enabled and "did not reproduce" in gd.disabled_reason
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(400)
 def test_flat_ddp_call_sequence_on_rccl(native):
     """The multi-GPU path's RCCL calls, run with one rank on this box (tests/rccl_single_rank.py); a child process
