@@ -58,6 +58,8 @@ def _declare(lib):
         "ptops_edge_norm_backward": (c_int, [P] * 10 + [c_int] * 6 + [ctypes.c_float] + [P] * 5),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
+        "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+        "ptops_max_tokens_backward": (c_int, [P, P, c_int, c_int, c_int, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
         "ptops_layer_norm_max_dim": (c_int, []),
         "ptops_layer_norm_forward": (c_int, [P, P, P, ctypes.c_longlong, c_int, ctypes.c_float, P, P, P, P]),
@@ -89,6 +91,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
+    "ptops_max_tokens_forward", "ptops_max_tokens_backward",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
@@ -165,53 +168,74 @@ def _same_device(*ts):
 
 
 # ------------------------------------------------------------------------------------------
-CHAMFER_AUTO, CHAMFER_BRUTE, CHAMFER_SWEEP = 0, 1, 2
+CHAMFER_AUTO, CHAMFER_BRUTE, CHAMFER_SWEEP, CHAMFER_MFMA = 0, 1, 2, 3
+CHAMFER_MFMA_MIN_CANDIDATES = 1024      # PTOPS_CHAMFER_MFMA_MIN_CANDIDATES of include/ptops.h
 
 
 class _ChamferPolicy:
-    """Per-shape, per-direction choice between the two exact Chamfer algorithms (bit-identical results).
+    """Per-shape, per-direction choice between the three exact Chamfer algorithms (bit-identical results).
 
-    The pruned sweep is ~3x faster than brute force when nearest neighbours are close (trained
-    predictions, well-spread clouds) and slower when they are not (e.g. uniform queries against a
-    prediction collapsed into a few clusters).  Every swept direction accumulates {chunks evaluated,
-    chunks a brute force would evaluate} on the device; the counters are copied to pinned host memory
-    without synchronising and looked at on a LATER call.  If more than `threshold` of the pairs still
-    had to be evaluated, that direction uses brute force for the next `hold` calls of the shape, then
-    the sweep is probed again."""
-    threshold = 0.5
+    * pruned sweep (both clouds 4096..16384 points): ~3x faster than brute force when nearest neighbours are close
+      (trained predictions, well-spread clouds), useless when they are not (uniform queries against a prediction
+      collapsed into a few clusters);
+    * MFMA filter (a direction that searches >= 1024 candidates): sees every pair on the matrix pipe, ~2x faster than
+      brute force whatever the geometry, unless masses of exactly tied distances (lattices, duplicated points) force
+      lanes into their exact scan;
+    * brute force: the VALU kernel.
+
+    Every swept / filtered direction accumulates {work done exactly, work a full scan would do} on the device; the
+    counters are copied to pinned host memory without synchronising and looked at on a LATER call.  A sweep that still
+    evaluated more than `sweep_threshold` of the chunks is demoted to the MFMA filter, an MFMA filter that re-evaluated
+    more than `mfma_threshold` of the superblocks exactly is demoted to brute force, each for the next `hold` calls of
+    the shape; then the preferred algorithm is probed again."""
+    sweep_threshold = 0.35
+    mfma_threshold = 0.04
     hold = 50
 
     def __init__(self):
         self.state = {}
 
-    def choose(self, key):
-        st = self.state.setdefault(key, dict(brute_left=[0, 0], pending=None))
+    @staticmethod
+    def _ladder(sweep_ok, n_candidates):
+        ladder = [CHAMFER_SWEEP] if sweep_ok else []
+        if n_candidates >= CHAMFER_MFMA_MIN_CANDIDATES:
+            ladder.append(CHAMFER_MFMA)
+        return ladder + [CHAMFER_BRUTE]
+
+    def choose(self, key, sweep_ok, n_candidates):
+        """-> ([algorithm of direction 0, of direction 1], state).  n_candidates = (m, n): what each direction searches."""
+        st = self.state.setdefault(key, dict(level=[0, 0], left=[0, 0], pending=None))
+        ladders = [self._ladder(sweep_ok, n_candidates[d]) for d in range(2)]
         pend = st["pending"]
         if pend is not None and pend[1].query():
-            vals = pend[0].tolist()
+            vals, used = pend[0].tolist(), pend[2]
             st["pending"] = None
             for d in range(2):
                 ev, tot = vals[2 * d], vals[2 * d + 1]
-                if tot > 0 and ev / tot > self.threshold:
-                    st["brute_left"][d] = self.hold
+                if tot <= 0 or used[d] not in ladders[d]:
+                    continue
+                limit = self.sweep_threshold if used[d] == CHAMFER_SWEEP else self.mfma_threshold
+                if used[d] != CHAMFER_BRUTE and ev / tot > limit:
+                    st["level"][d] = ladders[d].index(used[d]) + 1
+                    st["left"][d] = self.hold
         algos = []
         for d in range(2):
-            if st["brute_left"][d] > 0:
-                st["brute_left"][d] -= 1
-                algos.append(CHAMFER_BRUTE)
+            if st["left"][d] > 0:
+                st["left"][d] -= 1
             else:
-                algos.append(CHAMFER_SWEEP)
+                st["level"][d] = 0
+            algos.append(ladders[d][min(st["level"][d], len(ladders[d]) - 1)])
         return algos, st
 
     @staticmethod
-    def record(st, stats_dev):
+    def record(st, stats_dev, algos):
         if st is None or st["pending"] is not None:
             return
         host = torch.empty(4, dtype=torch.int64, pin_memory=True)
         host.copy_(stats_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        st["pending"] = (host, ev)
+        st["pending"] = (host, ev, tuple(algos))
 
 
 _chamfer_policy = _ChamferPolicy()
@@ -222,7 +246,7 @@ chamfer_algorithm_log = {}   # (B, n, m) -> algorithms of the most recent launch
 
 def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
     """chamfer.forward (extensions/chamfer_dist/chamfer_cuda.cpp:22-25).  `algorithm`: CHAMFER_AUTO
-    (adaptive per direction, see _ChamferPolicy), CHAMFER_BRUTE, CHAMFER_SWEEP, or a pair of those for
+    (adaptive per direction, see _ChamferPolicy), CHAMFER_BRUTE, CHAMFER_SWEEP, CHAMFER_MFMA, or a pair of those for
     (xyz1->xyz2, xyz2->xyz1) — the results are identical."""
     if _test_backend is not None:
         return _test_backend.chamfer_forward(xyz1, xyz2)
@@ -240,21 +264,21 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
         dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
         idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
         idx2 = torch.empty((B, m), dtype=torch.int32, device=dev)
+        if B == 0 or n == 0 or m == 0:
+            algos = [CHAMFER_BRUTE, CHAMFER_BRUTE]
         wsb = lib.ptops_chamfer_forward_workspace_bytes(B, n, m)
         ws = torch.empty(((wsb + 15) // 16 * 2,), dtype=torch.int64, device=dev) if wsb else None
         stats = st = None
-        if lib.ptops_chamfer_sweep_available(B, n, m):
-            if algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
-                algos, st = _chamfer_policy.choose((dev.index, B, n, m))
-                if CHAMFER_SWEEP in algos and st["pending"] is None:
-                    stats = torch.zeros(4, dtype=torch.int64, device=dev)
-        else:
-            algos = [CHAMFER_BRUTE if a == CHAMFER_AUTO else a for a in algos]
+        if algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
+            algos, st = _chamfer_policy.choose((dev.index, B, n, m), bool(lib.ptops_chamfer_sweep_available(B, n, m)),
+                                               (m, n))
+            if st["pending"] is None and any(a in (CHAMFER_SWEEP, CHAMFER_MFMA) for a in algos):
+                stats = torch.zeros(4, dtype=torch.int64, device=dev)
         _call("ptops_chamfer_forward_ex", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist1), _ptr(dist2),
               _ptr(idx1), _ptr(idx2), _ptr(ws) if ws is not None else None, int(algos[0]), int(algos[1]),
               _ptr(stats) if stats is not None else None, _stream(xyz1))
         if stats is not None:
-            _chamfer_policy.record(st, stats)
+            _chamfer_policy.record(st, stats, algos)
         chamfer_algorithm_log[(B, n, m)] = tuple(int(a) for a in algos)
     return dist1, dist2, idx1, idx2
 
@@ -572,6 +596,34 @@ def colsum(x):
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
         _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
     return out
+
+
+def max_tokens_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.size(2) % 4 == 0 and x.size(1) >= 1 \
+        and x.size(0) <= 65535
+
+
+def max_tokens_forward(x):
+    """x [B,M,C] float32 contiguous (C % 4 == 0) -> (max over tokens [B,C], arg-max token int32 [B,C])."""
+    _check(x, "x", torch.float32, 3)
+    B, M, C = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        _call("ptops_max_tokens_forward", _ptr(x), B, M, C, _ptr(out), _ptr(arg), _stream(x))
+    return out, arg
+
+
+def max_tokens_backward(grad_out, arg, M):
+    """grad_out [B,C], arg int32 [B,C] -> grad_x [B,M,C] (every element written)."""
+    _check(grad_out, "grad_out", torch.float32, 2)
+    _check(arg, "arg", torch.int32, 2)
+    _same_device(grad_out, arg)
+    B, C = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        gx = torch.empty((B, int(M), C), dtype=torch.float32, device=grad_out.device)
+        _call("ptops_max_tokens_backward", _ptr(grad_out), _ptr(arg), B, int(M), C, _ptr(gx), _stream(grad_out))
+    return gx
 
 
 def _scratch(dev, stream, need):

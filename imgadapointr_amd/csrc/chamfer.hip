@@ -297,10 +297,14 @@ static size_t brute_workspace_bytes(int B, int n, int m) {
   return p.need_ws ? sizeof(unsigned long long) * (size_t)B * ((size_t)n + m) : 0;
 }
 
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
 PTOPS_API size_t ptops_chamfer_forward_workspace_bytes(int B, int n, int m) {
   if (B <= 0 || n <= 0 || m <= 0) return 0;
-  // room for both algorithms at once: the two directions of one call may use different ones
-  return brute_workspace_bytes(B, n, m) + (use_sweep(B, n, m) ? ptops_sweep::workspace_bytes(B, n, m) : 0);
+  // room for all algorithms at once: the two directions of one call may use different ones
+  // layout: [sweep: sorted clouds | mfma: operands, bounds, packed minima | brute: packed minima]
+  return align256(use_sweep(B, n, m) ? ptops_sweep::workspace_bytes(B, n, m) : 0) +
+         align256(ptops_mfma::workspace_bytes(B, n, m)) + brute_workspace_bytes(B, n, m);
 }
 
 PTOPS_API int ptops_chamfer_sweep_available(int B, int n, int m) {
@@ -330,8 +334,8 @@ static int brute_forward(const float* xyz1, const float* xyz2, int B, int n, int
       ptops::set_error("chamfer_forward: workspace must be 8-byte aligned");
       return PTOPS_EALIGN;
     }
-    if (split[0]) (void)hipMemsetAsync(ws, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream);
-    if (split[1]) (void)hipMemsetAsync(ws + (size_t)B * n, 0xFF, sizeof(unsigned long long) * (size_t)B * m, stream);
+    if (split[0]) (void)ptops::fill_async(ws, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream);
+    if (split[1]) (void)ptops::fill_async(ws + (size_t)B * n, 0xFF, sizeof(unsigned long long) * (size_t)B * m, stream);
   }
   Args a;
   const long long blocks0 = on[0] ? (long long)B * p.qtiles[0] * p.splits[0] : 0;
@@ -371,42 +375,55 @@ PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int
   hipStream_t stream = (hipStream_t)stream_;
   const int algo[2] = {algorithm1, algorithm2};
   for (int d = 0; d < 2; ++d)
-    PTOPS_REQUIRE(algo[d] == PTOPS_CHAMFER_AUTO || algo[d] == PTOPS_CHAMFER_BRUTE || algo[d] == PTOPS_CHAMFER_SWEEP,
+    PTOPS_REQUIRE(algo[d] == PTOPS_CHAMFER_AUTO || algo[d] == PTOPS_CHAMFER_BRUTE || algo[d] == PTOPS_CHAMFER_SWEEP ||
+                      algo[d] == PTOPS_CHAMFER_MFMA,
                   "chamfer_forward: unknown algorithm %d", algo[d]);
   PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_forward: negative size");
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(dist1 && dist2 && idx1 && idx2, "chamfer_forward: null output");
   if (n == 0 || m == 0) {  // the reference returns its zero-initialised outputs (chamfer.cu:152-157)
-    if (n) (void)hipMemsetAsync(dist1, 0, sizeof(float) * (size_t)B * n, stream), (void)hipMemsetAsync(idx1, 0, sizeof(int32_t) * (size_t)B * n, stream);
-    if (m) (void)hipMemsetAsync(dist2, 0, sizeof(float) * (size_t)B * m, stream), (void)hipMemsetAsync(idx2, 0, sizeof(int32_t) * (size_t)B * m, stream);
+    if (n) (void)ptops::fill_async(dist1, 0, sizeof(float) * (size_t)B * n, stream), (void)ptops::fill_async(idx1, 0, sizeof(int32_t) * (size_t)B * n, stream);
+    if (m) (void)ptops::fill_async(dist2, 0, sizeof(float) * (size_t)B * m, stream), (void)ptops::fill_async(idx2, 0, sizeof(int32_t) * (size_t)B * m, stream);
     return ptops::check_launch("chamfer_forward(memset)");
   }
   PTOPS_REQUIRE(xyz1 && xyz2, "chamfer_forward: null input");
   PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
                 "chamfer_forward: B*n*3 must fit int32");
   const bool can_sweep = use_sweep(B, n, m);
-  int sweep_mask = 0;
+  const int nc[2] = {m, n};   // candidates searched by direction d
+  int sweep_mask = 0, mfma_mask = 0;
   for (int d = 0; d < 2; ++d) {
     PTOPS_REQUIRE(algo[d] != PTOPS_CHAMFER_SWEEP || can_sweep,
                   "chamfer_forward: the sweep needs both clouds within [4096, 16384] points (n=%d m=%d)", n, m);
-    if (can_sweep && algo[d] != PTOPS_CHAMFER_BRUTE) sweep_mask |= 1 << d;
+    if (algo[d] == PTOPS_CHAMFER_SWEEP || (algo[d] == PTOPS_CHAMFER_AUTO && can_sweep)) sweep_mask |= 1 << d;
+    else if (algo[d] == PTOPS_CHAMFER_MFMA ||
+             (algo[d] == PTOPS_CHAMFER_AUTO && nc[d] >= PTOPS_CHAMFER_MFMA_MIN_CANDIDATES)) mfma_mask |= 1 << d;
   }
-  // workspace layout: [sorted clouds for the sweep | packed minima for split brute force]
+  // workspace layout: see ptops_chamfer_forward_workspace_bytes
   char* wsp = (char*)workspace;
-  const size_t sweep_bytes = can_sweep ? ptops_sweep::workspace_bytes(B, n, m) : 0;
-  if (sweep_mask) {
+  const size_t sweep_bytes = align256(can_sweep ? ptops_sweep::workspace_bytes(B, n, m) : 0);
+  const size_t mfma_bytes = align256(ptops_mfma::workspace_bytes(B, n, m));
+  if (sweep_mask || mfma_mask) {
     PTOPS_REQUIRE(wsp != nullptr, "chamfer_forward: workspace required (%zu bytes)",
                   ptops_chamfer_forward_workspace_bytes(B, n, m));
     if (((uintptr_t)wsp & 15) != 0) {
       ptops::set_error("chamfer_forward: workspace must be 16-byte aligned");
       return PTOPS_EALIGN;
     }
+  }
+  if (sweep_mask) {
     int rc = ptops_sweep::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, wsp, stats, sweep_mask, stream);
     if (rc != PTOPS_OK) return rc;
   }
-  if (sweep_mask == 3) return PTOPS_OK;
+  if (mfma_mask) {
+    int rc = ptops_mfma::forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, wsp + sweep_bytes, stats, mfma_mask,
+                                 stream);
+    if (rc != PTOPS_OK) return rc;
+  }
+  if ((sweep_mask | mfma_mask) == 3) return PTOPS_OK;
   return brute_forward(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2,
-                       wsp ? (unsigned long long*)(wsp + sweep_bytes) : nullptr, 3 & ~sweep_mask, stream);
+                       wsp ? (unsigned long long*)(wsp + sweep_bytes + mfma_bytes) : nullptr,
+                       3 & ~(sweep_mask | mfma_mask), stream);
 }
 
 PTOPS_API int ptops_chamfer_backward(const float* xyz1, const float* xyz2, const int32_t* idx1,
@@ -417,8 +434,8 @@ PTOPS_API int ptops_chamfer_backward(const float* xyz1, const float* xyz2, const
   PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_backward: negative size");
   if (B == 0) return PTOPS_OK;
   if (n == 0 || m == 0) {
-    if (n) (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, stream);
-    if (m) (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, stream);
+    if (n) (void)ptops::fill_async(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, stream);
+    if (m) (void)ptops::fill_async(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, stream);
     return ptops::check_launch("chamfer_backward(memset)");
   }
   PTOPS_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_dist1 && grad_dist2 && grad_xyz1 && grad_xyz2,

@@ -213,7 +213,7 @@ PTOPS_API int ptops_emd_forward(const float* xyz1, const float* xyz2, int B, int
                 "emd_forward: null pointer");
   (void)unass_cnt_sum;  // the reference's cross-batch prefix sums are not needed: lists are per cloud
   (void)cnt_tmp;
-  (void)hipMemsetAsync(max_idx, 0x7f, sizeof(int32_t) * (size_t)B * n, stream);
+  (void)ptops::fill_async(max_idx, 0x7f, sizeof(int32_t) * (size_t)B * n, stream);
   const dim3 per_point(n / 256, B), bidg(n / (4 * kP), B);
   for (int it = 0; it < iters; ++it) {
     hipLaunchKernelGGL(emd_compact_kernel, dim3(B), dim3(1024), 0, stream, n, assignment, unass_idx, unass_cnt);

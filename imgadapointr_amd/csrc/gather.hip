@@ -323,7 +323,7 @@ PTOPS_API int ptops_gather_backward(const float* grad_out, const int32_t* idx, i
   PTOPS_REQUIRE(B >= 0 && C >= 0 && N >= 1 && npoint >= 0, "gather_backward: bad size");
   if ((long long)B * C * N == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_feat, "gather_backward: null pointer");
-  (void)hipMemsetAsync(grad_feat, 0, sizeof(float) * (size_t)B * C * N, stream);
+  (void)ptops::fill_async(grad_feat, 0, sizeof(float) * (size_t)B * C * N, stream);
   const long long total = (long long)B * C * npoint;
   if (total == 0) return ptops::check_launch("gather_backward(memset)");
   PTOPS_REQUIRE(grad_out && idx, "gather_backward: null pointer");
@@ -357,7 +357,7 @@ PTOPS_API int ptops_index_points_backward(const float* grad_out, const int32_t* 
   PTOPS_REQUIRE(B >= 0 && N >= 1 && C >= 1 && S >= 0 && k >= 0, "index_points_backward: bad size");
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_points, "index_points_backward: null pointer");
-  (void)hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * N * C, stream);
+  (void)ptops::fill_async(grad_points, 0, sizeof(float) * (size_t)B * N * C, stream);
   const long long total = (long long)B * S * k * C;
   if (total == 0) return ptops::check_launch("index_points_backward(memset)");
   PTOPS_REQUIRE(grad_out && idx, "index_points_backward: null pointer");
@@ -392,7 +392,7 @@ PTOPS_API int ptops_edge_group_backward(const float* grad_out, const int32_t* id
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_xk && (grad_xq || Nq == 0), "edge_group_backward: null pointer");
   if (Nq == 0) {
-    (void)hipMemsetAsync(grad_xk, 0, sizeof(float) * (size_t)B * C * Nk, stream);
+    (void)ptops::fill_async(grad_xk, 0, sizeof(float) * (size_t)B * C * Nk, stream);
     return ptops::check_launch("edge_group_backward(memset)");
   }
   PTOPS_REQUIRE(grad_out && idx, "edge_group_backward: null pointer");
@@ -413,7 +413,7 @@ PTOPS_API int ptops_edge_group_backward(const float* grad_out, const int32_t* id
     }
     return ptops::check_launch("edge_group_bwd_lds_kernel");
   }
-  (void)hipMemsetAsync(grad_xk, 0, sizeof(float) * (size_t)B * C * Nk, stream);
+  (void)ptops::fill_async(grad_xk, 0, sizeof(float) * (size_t)B * C * Nk, stream);
   const long long total = (long long)B * C * Nq;
   hipLaunchKernelGGL(edge_group_bwd_generic_kernel, dim3(grid_for(total)), dim3(kTPB), 0, stream, grad_out,
                      idx, C, Nk, Nq, k, total, grad_xk, grad_xq);
@@ -454,7 +454,7 @@ PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* ar
                        arg, N, C, S, grad_p);
     return ptops::check_launch("gather_max_bwd_lds_kernel");
   }
-  (void)hipMemsetAsync(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);
+  (void)ptops::fill_async(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);
   if (total == 0) return ptops::check_launch("gather_max_backward(memset)");
   PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
   hipLaunchKernelGGL(gather_max_bwd_kernel, dim3(grid_for(total)), dim3(kTPB), 0, stream, grad_out, arg, N,

@@ -271,7 +271,7 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   PTOPS_REQUIRE(ln_args_ok(rows, C), "layer_norm_backward: need rows >= 0, C %% 4 == 0, 4 <= C <= 1024 (C=%d)", C);
   PTOPS_REQUIRE(dgamma_dbeta != nullptr, "layer_norm_backward: null output");
   if (rows == 0) {
-    (void)hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 3 * (size_t)C, stream);
+    (void)ptops::fill_async(dgamma_dbeta, 0, sizeof(float) * 3 * (size_t)C, stream);
     return ptops::check_launch("layer_norm_backward(memset)");
   }
   PTOPS_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "layer_norm_backward: null pointer");

@@ -25,6 +25,9 @@ inline int check_launch(const char* what) {
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
+// memset(ptr, value, bytes) as a kernel on `stream` (never a hipMemsetAsync: see core.hip)
+int fill_async(void* ptr, int value, size_t bytes, hipStream_t stream);
+
 constexpr int kNumCU = 256;   // MI355X
 constexpr int kWave = 64;
 
@@ -43,6 +46,15 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
             int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, int dirmask,
             hipStream_t stream);
 }  // namespace ptops_sweep
+
+// chamfer_mfma.hip: exact Chamfer search with an fp32 MFMA filter + exact re-evaluation
+namespace ptops_mfma {
+bool eligible(int B, int n, int m);
+size_t workspace_bytes(int B, int n, int m);
+int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
+            int32_t* idx1, int32_t* idx2, void* workspace, unsigned long long* stats, int dirmask,
+            hipStream_t stream);
+}  // namespace ptops_mfma
 
 #define PTOPS_REQUIRE(cond, ...)        \
   do {                                  \

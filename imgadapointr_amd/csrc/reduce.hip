@@ -121,7 +121,7 @@ PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* works
   PTOPS_REQUIRE(M >= 0 && N >= 1, "colsum: bad size");
   PTOPS_REQUIRE(out != nullptr, "colsum: null output");
   if (M == 0) {
-    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, stream);
+    (void)ptops::fill_async(out, 0, sizeof(float) * (size_t)N, stream);
     return ptops::check_launch("colsum(memset)");
   }
   PTOPS_REQUIRE(x && workspace, "colsum: null pointer");
@@ -132,4 +132,107 @@ PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* works
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ptops::ceil_div(N, 64), S), dim3(256), 0, stream, x, M, N,
                      (float*)workspace);
   return ptops_reduce::fold_rows((const float*)workspace, S, N, out, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Max over the tokens of [B,M,C] -> [B,C] with the arg-max token (torch.max(x, dim=1) of the global-feature pools,
+// models/external/AdaPoinTr.py:110,225 and models/base_blocks.py:759 of the reference).  One launch, no scratch and no
+// memset: ATen's strided reduction stages partial results behind semaphores that it zeroes with a MEMSET node, which
+// does not survive in a replayed HIP graph (core.hip).  16 lanes x float4 cover 64 channels of a row; the 16 row
+// groups of a workgroup fold through LDS.  Lowest token wins ties; a NaN wins over everything, as in torch.
+namespace {
+
+__global__ __launch_bounds__(256) void max_tokens_fwd_kernel(const float* __restrict__ x, int M, int C,
+                                                             float* __restrict__ out, int32_t* __restrict__ arg) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c0 = (blockIdx.x * 16 + tx) * 4;
+  const int b = blockIdx.y;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};   // a row group without rows (M < 16) never wins a tie
+  if (c0 < C) {
+    const float* xb = x + (size_t)b * M * C + c0;
+    for (int m = ty; m < M; m += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)m * C);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool take = e[i] > best[i] || (e[i] != e[i] && best[i] == best[i]) || m == ty;   // first row always; rows ascend
+        best[i] = take ? e[i] : best[i];
+        bi[i] = take ? m : bi[i];
+      }
+    }
+  }
+  __shared__ float sv[16][16][4];
+  __shared__ int si[16][16][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sv[ty][tx][i] = best[i];
+    si[ty][tx][i] = bi[i];
+  }
+  __syncthreads();
+  if (ty == 0 && c0 < C) {
+    float r[4];
+    int ri[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = sv[0][tx][i];
+      ri[i] = si[0][tx][i];
+    }
+    for (int g = 1; g < 16; ++g) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = sv[g][tx][i];
+        const int vi = si[g][tx][i];
+        const bool r_nan = r[i] != r[i], v_nan = v != v;
+        // larger value, or equal value at a lower token, or the first NaN
+        const bool take = (!r_nan && (v_nan || v > r[i] || (v == r[i] && vi < ri[i]))) || (r_nan && v_nan && vi < ri[i]);
+        r[i] = take ? v : r[i];
+        ri[i] = take ? vi : ri[i];
+      }
+    }
+    *reinterpret_cast<float4*>(out + (size_t)b * C + c0) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<int4*>(arg + (size_t)b * C + c0) = make_int4(ri[0], ri[1], ri[2], ri[3]);
+  }
+}
+
+// grad_x[b,m,c] = (arg[b,c] == m) ? g[b,c] : 0, every element written once (no zero fill, no scatter)
+__global__ __launch_bounds__(256) void max_tokens_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ arg,
+                                                             int M, int C4, long long total4, float* __restrict__ gx) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
+    const int c4 = (int)(i % C4);
+    const long long bm = i / C4;
+    const int m = (int)(bm % M);
+    const long long b = bm / M;
+    const float4 gv = reinterpret_cast<const float4*>(g)[b * C4 + c4];
+    const int4 av = reinterpret_cast<const int4*>(arg)[b * C4 + c4];
+    reinterpret_cast<float4*>(gx)[i] = make_float4(av.x == m ? gv.x : 0.f, av.y == m ? gv.y : 0.f,
+                                                   av.z == m ? gv.z : 0.f, av.w == m ? gv.w : 0.f);
+  }
+}
+
+}  // namespace
+
+PTOPS_API int ptops_max_tokens_forward(const float* x, int B, int M, int C, float* out, int32_t* arg, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && M >= 1 && C >= 4 && C % 4 == 0, "max_tokens_forward: need M >= 1 and C a multiple of 4");
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(x && out && arg, "max_tokens_forward: null pointer");
+  PTOPS_REQUIRE(B <= 65535, "max_tokens_forward: B too large");
+  hipLaunchKernelGGL(max_tokens_fwd_kernel, dim3((unsigned)ptops::ceil_div(C / 4, 16), (unsigned)B), dim3(256), 0, stream,
+                     x, M, C, out, arg);
+  return ptops::check_launch("max_tokens_fwd_kernel");
+}
+
+PTOPS_API int ptops_max_tokens_backward(const float* grad_out, const int32_t* arg, int B, int M, int C, float* grad_x,
+                                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && M >= 1 && C >= 4 && C % 4 == 0, "max_tokens_backward: need M >= 1 and C a multiple of 4");
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(grad_out && arg && grad_x, "max_tokens_backward: null pointer");
+  const long long total4 = (long long)B * M * (C / 4);
+  const long long blocks = ptops::ceil_div_ll(total4, 256 * 4);
+  hipLaunchKernelGGL(max_tokens_bwd_kernel, dim3((unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192)), dim3(256), 0,
+                     stream, grad_out, arg, M, C / 4, total4, grad_x);
+  return ptops::check_launch("max_tokens_bwd_kernel");
 }

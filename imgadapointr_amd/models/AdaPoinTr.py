@@ -20,7 +20,8 @@ from ..pointnet2_ops import pointnet2_utils
 from .base_blocks import (DGCNN_Grouper, Fold, PointTransformerDecoderEntry, PointTransformerEncoderEntry,
                           SimpleRebuildFCLayer, trunc_normal_)
 from .build import MODELS
-from .Transformer_utils import GELU, Linear, _LinearFn, index_points, knn_idx, linear_on_broadcast_concat
+from .Transformer_utils import (GELU, Linear, _LinearFn, index_points, knn_idx, linear_on_broadcast_concat,
+                                max_over_tokens)
 
 # True: AdaPoinTr.increase_dim (Conv1d 1x1 -> BatchNorm1d -> LeakyReLU -> Conv1d 1x1) runs token-major as two GEMMs
 TOKEN_MAJOR_INCREASE_DIM = True
@@ -131,7 +132,7 @@ class PCTransformer(nn.Module):
         x = self.encoder(x + pe, coor)
         x = self.fuse_encoder_tokens(x, coor, img, cls_vec)
         global_feature = self.increase_dim(x)
-        global_feature = torch.max(global_feature, dim=1)[0]               # [B,1024]
+        global_feature = max_over_tokens(global_feature)                   # [B,1024]
 
         coarse = self.coarse_pred(global_feature).reshape(bs, -1, 3)
         coarse_inp = pointnet2_utils.gather_operation(
@@ -247,7 +248,7 @@ class AdaPoinTr(nn.Module):
         B, M, C = q.shape
 
         global_feature = self._increase_dim(q)                                   # [B,M,1024]
-        global_feature = torch.max(global_feature, dim=1)[0]
+        global_feature = max_over_tokens(global_feature.contiguous())
         # reduce_map(cat([global_feature broadcast (1024), q (C), coarse (3)])), AdaPoinTr.py:226-239
         rebuild_feature = linear_on_broadcast_concat(
             self.reduce_map, global_feature, torch.cat([q, coarse_point_cloud], dim=-1))

@@ -199,6 +199,34 @@ def add_layer_norm(x, res, norm):
     return s, norm(s)
 
 
+class _MaxTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        out, arg = _native.max_tokens_forward(x)
+        ctx.save_for_backward(arg)
+        ctx.tokens = x.size(1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return _native.max_tokens_backward(g.contiguous(), arg, ctx.tokens)
+
+
+FAST_MAX_TOKENS = True
+
+
+def max_over_tokens(x):
+    """torch.max(x, dim=1)[0] for token features x [B,M,C] (the global-feature pools of AdaPoinTr.py:110,225 and
+    base_blocks.py:759).  On the GPU one libptops kernel each way: ATen's strided reduction zeroes its semaphores with
+    a memset, and a MEMSET node in a replayed HIP graph is not reliable on this stack (csrc/core.hip) — this is what
+    keeps the validation forward graph-safe; the backward writes the gradient once instead of zero-fill + scatter."""
+    if (FAST_MAX_TOKENS and _native.backend_for_testing() is None and x.dim() == 3 and x.is_contiguous()
+            and _native.max_tokens_supported(x)):
+        return _MaxTokensFn.apply(x)
+    return torch.max(x, dim=1)[0]
+
+
 # ------------------------------------------------------------------------------ functional
 def knn_idx(nsample, xyz, new_xyz):
     """int32 [B,S,nsample] neighbour indices, ordered by (distance, index).  No gradient."""

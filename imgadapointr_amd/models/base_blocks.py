@@ -20,7 +20,7 @@ from .. import _native
 from ..pointnet2_ops import pointnet2_utils
 from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerNorm, LayerScale, Linear, Mlp,
                                 add_layer_norm,
-                                knn_idx, linear_on_broadcast_concat)
+                                knn_idx, linear_on_broadcast_concat, max_over_tokens)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
 
@@ -550,7 +550,7 @@ class SimpleRebuildFCLayer(nn.Module):
 
     def forward(self, rec_feature):
         batch_size = rec_feature.size(0)
-        g_feature = rec_feature.max(1)[0]
+        g_feature = max_over_tokens(rec_feature.contiguous())
         # self.layer(cat([g_feature broadcast, rec_feature])) with the first Linear split
         mlp = self.layer
         h = linear_on_broadcast_concat(mlp.fc1, g_feature, rec_feature)

@@ -23,6 +23,7 @@ import torch.nn as nn
 from ..extensions.chamfer_dist import ChamferDistanceL2
 from .build import MODELS
 from .pointwise import run_parts, run_points, run_rows
+from .Transformer_utils import max_over_tokens
 
 
 def _stack(widths, norm_last=False):
@@ -65,7 +66,7 @@ class _PointNetCompletion(nn.Module):
         feature = run_points(self.first_conv, xyz)                                # [B,n,256]
         pooled = feature.max(dim=1, keepdim=True)[0]                              # [B,1,256]
         feature = run_parts(self.second_conv, [pooled, feature])                  # cat order: pooled, per-point
-        return feature.max(dim=1)[0]
+        return max_over_tokens(feature.contiguous())
 
 
 @MODELS.register_module()

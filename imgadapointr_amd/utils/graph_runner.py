@@ -11,8 +11,10 @@ Safety rules (a graph that silently replays the wrong thing is worse than no gra
     current device is captured on ITS stream (otherwise the kernels would run eagerly there while an empty graph is
     recorded on the current device and every later replay would return the first call's outputs);
   * all inputs must live on one device, which is part of the cache key;
-  * after capture the graph is replayed once and compared with the eager warm-up outputs; a mismatch (or an empty
-    graph) disables graphing for this model and says why;
+  * after capture the graph is put through a self-test (unrelated work, a host synchronisation, a replay on
+    perturbed inputs, a replay on the original ones) against eager forwards; a mismatch — an empty graph, a stateful
+    forward, a graph node that does not survive replays (MEMSET nodes on this stack) — disables graphing for this
+    model and says why;
   * only capture failures (RuntimeError / TypeError from the stream capture) fall back to eager, and the reason is
     logged; an out-of-memory error is re-raised;
   * at most `max_graphs` captured signatures are kept (least recently used is dropped together with its memory pool).
@@ -101,18 +103,45 @@ class GraphedForward:
             self._disable(f"outputs are not on the inputs' device {device}")
             return None
         if self.verify:
-            eager_flat, _ = _flatten(eager)
-            for t in flat:                            # a graph that recorded nothing leaves these untouched
-                t.fill_(float("nan")) if t.is_floating_point() else t.zero_()
-            graph.replay()
-            torch.cuda.synchronize(device)
-            ok = eager_flat is not None and len(eager_flat) == len(flat) and all(
-                (torch.allclose(a, b, rtol=self.rtol, atol=self.atol) if a.is_floating_point() else torch.equal(a, b))
-                for a, b in zip(flat, eager_flat))
-            if not ok:
-                self._disable("a replay did not reproduce the eager forward")
+            reason = self._self_test(static_in, graph, flat, eager, device)
+            if reason is not None:
+                self._disable(reason)
                 return None
         return static_in, graph, flat, rebuild
+
+    def _matches(self, flat, eager_out):
+        eager_flat, _ = _flatten(eager_out)
+        return eager_flat is not None and len(eager_flat) == len(flat) and all(
+            (torch.allclose(a, b, rtol=self.rtol, atol=self.atol, equal_nan=True) if a.is_floating_point()
+             else torch.equal(a, b)) for a, b in zip(flat, eager_flat))
+
+    def _self_test(self, static_in, graph, flat, eager, device):
+        """Replays the fresh graph the way validation will use it and compares with eager forwards.  -> reason or None.
+
+        The sequence is the one that exposes a graph which does not survive real use on this stack: unrelated
+        allocations and kernels, a HOST SYNCHRONISATION, then a replay on inputs that differ from the captured ones.
+        (A MEMSET node in a replayed HIP graph stops taking effect after a host synchronisation — csrc/core.hip,
+        benchmarks/graph_diag3.py: stale outputs from ATen's strided reductions, whose semaphores are zeroed by
+        memset.  An empty graph, i.e. kernels that ran eagerly on another device during capture, fails here too.)"""
+        originals = [t.clone() for t in static_in]
+        scratch = torch.zeros(1024, device=device) + 1.0
+        torch.cuda.synchronize(device)
+        perturbed = [t.roll(1, dims=max(t.dim() - 2, 0)) if t.numel() > 1 else t.clone() for t in originals]
+        want = self.model(*perturbed)
+        for s, t in zip(static_in, perturbed):
+            s.copy_(t)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        if not self._matches(flat, want):
+            return "a replay after a host synchronisation did not reproduce the eager forward on new inputs"
+        for s, t in zip(static_in, originals):
+            s.copy_(t)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        del scratch
+        if not self._matches(flat, eager):
+            return "a replay did not reproduce the eager forward"
+        return None
 
     def __call__(self, *inputs):
         if not self._eligible(inputs):

@@ -48,17 +48,26 @@ int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, in
                           void* workspace, void* stream);
 
 /* Same operator with an explicit algorithm per direction (algorithm1: xyz1 -> xyz2, dist1/idx1;
- * algorithm2: xyz2 -> xyz1).  Both algorithms return bit-identical results:
+ * algorithm2: xyz2 -> xyz1).  All algorithms return bit-identical results:
  *   PTOPS_CHAMFER_BRUTE  every pair is evaluated (VALU-issue bound);
  *   PTOPS_CHAMFER_SWEEP  clouds are sorted by x and every query tile sweeps outwards until no farther
  *                        candidate can win or tie (exact pruning; needs ptops_chamfer_sweep_available);
- *   PTOPS_CHAMFER_AUTO   the sweep whenever it is available.
+ *   PTOPS_CHAMFER_MFMA   one v_mfma_f32_16x16x4_f32 per 16 x 16 pairs evaluates |c|^2 - 2 c.q as a FILTER with a
+ *                        proven error bound; the one or two 64-candidate superblocks per lane that can hold the
+ *                        nearest neighbour are re-evaluated with the exact direct-difference arithmetic (every pair
+ *                        is seen, the vector pipe only keeps minima; matrix-pipe bound);
+ *   PTOPS_CHAMFER_AUTO   the sweep whenever it is available, else the MFMA filter for directions that search at
+ *                        least PTOPS_CHAMFER_MFMA_MIN_CANDIDATES points, else brute force.
  * stats (optional, 4 x u64, device memory, caller-zeroed): a swept direction d adds {16-candidate chunks
- * evaluated, chunks a brute force would evaluate} to stats[2d], stats[2d+1], so that a caller can steer the
+ * evaluated, chunks a brute force would evaluate} to stats[2d], stats[2d+1]; an MFMA-filtered direction adds
+ * {64-candidate superblocks re-evaluated exactly beyond the one every lane needs, superblocks visited} (per lane), so
+ * that a caller can steer the
  * choice for the following calls. */
 #define PTOPS_CHAMFER_AUTO 0
 #define PTOPS_CHAMFER_BRUTE 1
 #define PTOPS_CHAMFER_SWEEP 2
+#define PTOPS_CHAMFER_MFMA 3
+#define PTOPS_CHAMFER_MFMA_MIN_CANDIDATES 1024
 int ptops_chamfer_sweep_available(int B, int n, int m);
 int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m,
                              float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
@@ -283,6 +292,15 @@ int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const flo
  * ptops_colsum_workspace_bytes(M, N) bytes, 16-byte aligned. */
 size_t ptops_colsum_workspace_bytes(int M, int N);
 int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
+
+/* ---------------------------------------------------------- max over tokens --
+ * out[b,c] = max_m x[b,m,c], arg[b,c] = the (lowest) token that attains it, for row-major fp32 x [B,M,C]
+ * (C % 4 == 0): torch.max(x, dim=1) of the global-feature pools (models/external/AdaPoinTr.py:110,225,
+ * models/base_blocks.py:759).  backward: grad_x[b,m,c] = grad_out[b,c] if m == arg[b,c] else 0, fully written.
+ * One kernel each, no scratch memory, no memset (safe under HIP-graph capture). */
+int ptops_max_tokens_forward(const float* x, int B, int M, int C, float* out, int32_t* arg, void* stream);
+int ptops_max_tokens_backward(const float* grad_out, const int32_t* arg, int B, int M, int C, float* grad_x,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,10 +58,11 @@ def test_chamfer_forward_bit_exact(native, ref, B, n, m, kind):
     rng = np.random.default_rng(B * 1000003 + n * 101 + m)
     a, b = _cloud(rng, B, n, kind), _cloud(rng, B, m, kind)
     r1, r2, j1, j2 = ref.chamfer_forward(a, b)
-    algos = [native.CHAMFER_BRUTE, native.CHAMFER_AUTO]
+    algos = [native.CHAMFER_BRUTE, native.CHAMFER_AUTO, native.CHAMFER_MFMA,
+             (native.CHAMFER_MFMA, native.CHAMFER_BRUTE), (native.CHAMFER_BRUTE, native.CHAMFER_MFMA)]
     if native.load().ptops_chamfer_sweep_available(B, n, m):
         algos += [native.CHAMFER_SWEEP, (native.CHAMFER_SWEEP, native.CHAMFER_BRUTE),
-                  (native.CHAMFER_BRUTE, native.CHAMFER_SWEEP)]
+                  (native.CHAMFER_MFMA, native.CHAMFER_SWEEP)]
     for algo in algos:   # every algorithm must reproduce the oracle bit for bit
         d1, d2, i1, i2 = native.chamfer_forward(_t(a), _t(b), algorithm=algo)
         assert np.array_equal(d1.cpu().numpy().view(np.uint32), r1.view(np.uint32)), algo
@@ -77,34 +78,69 @@ def test_chamfer_mixed_kinds(native, ref):
                          ("clusters", "lattice", 5000, 4500)):
         a, b = _cloud(rng, 2, n, ka), _cloud(rng, 2, m, kb)
         want = ref.chamfer_forward(a, b)
-        for algo in (native.CHAMFER_SWEEP, native.CHAMFER_BRUTE):
+        for algo in (native.CHAMFER_SWEEP, native.CHAMFER_BRUTE, native.CHAMFER_MFMA):
             got = native.chamfer_forward(_t(a), _t(b), algorithm=algo)
             for g, w in zip(got, want):
                 assert np.array_equal(g.cpu().numpy(), w), (ka, kb, algo)
 
 
+@pytest.mark.parametrize("kind,scale,shift", [("uniform", 1.0, 0.0), ("uniform", 1000.0, 0.0), ("uniform", 1e-3, 0.0),
+                                              ("uniform", 1.0, 100.0), ("clusters", 1.0, 3.0), ("dups", 50.0, -7.0),
+                                              ("lattice", 1.0, 0.0)])
+def test_chamfer_mfma_filter_error_bound(native, ref, kind, scale, shift):
+    """The MFMA filter's error bound scales with (|c|max + |q|)^2: clouds far from the origin, tiny and huge clouds,
+    and masses of exact ties (every lane falls back to its exact scan) must all stay bit-exact."""
+    rng = np.random.default_rng(int(scale * 7 + shift * 13) + len(kind))
+    B, n, m = 2, 3000, 2100
+    a = (_cloud(rng, B, n, kind) * np.float32(scale) + np.float32(shift)).astype(np.float32)
+    b = (_cloud(rng, B, m, kind) * np.float32(scale) + np.float32(shift)).astype(np.float32)
+    want = ref.chamfer_forward(a, b)
+    got = native.chamfer_forward(_t(a), _t(b), algorithm=native.CHAMFER_MFMA)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32)), (kind, scale, shift)
+
+
 def test_chamfer_adaptive_policy(native):
-    """The adaptive choice never changes results; a direction that cannot prune backs off to brute force."""
+    """The adaptive choice never changes results; a direction whose sweep cannot prune is demoted to the MFMA filter,
+    and an MFMA filter drowning in exact ties is demoted to brute force."""
     key = (0, 4, 8192, 8192)
-    native._chamfer_policy.state.clear()
+    pol = native._chamfer_policy
+    pol.state.clear()
     gt = torch.rand(4, 8192, 3, device="cuda") - 0.5
     blob = (torch.randn(4, 8192, 3, device="cuda") * 1e-3)           # the whole cloud in one tiny cluster
     ref_out = native.chamfer_forward(blob, gt, algorithm=native.CHAMFER_BRUTE)
-    backed_off = [0, 0]
+    level = [0, 0]
+    seen = set()
     for _ in range(6):
         out = native.chamfer_forward(blob, gt)
+        seen.add(native.chamfer_algorithm_log[(4, 8192, 8192)])
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(out, ref_out))
         for d in range(2):
-            backed_off[d] = max(backed_off[d], native._chamfer_policy.state[key]["brute_left"][d])
-    # uniform queries against one cluster (direction 2) cannot prune; cluster queries against a uniform cloud can
-    assert backed_off[1] > 0 and backed_off[0] == 0, backed_off
-    native._chamfer_policy.state.clear()
+            level[d] = max(level[d], pol.state[key]["level"][d])
+    # uniform queries against one cluster (direction 2) cannot prune: MFMA filter; cluster queries against a uniform
+    # cloud can: the sweep stays
+    assert level == [0, 1], level
+    assert (native.CHAMFER_SWEEP, native.CHAMFER_MFMA) in seen, seen
+    pol.state.clear()
     near = gt + torch.randn_like(gt) * 0.005                          # prediction close to the target
     for _ in range(6):
         native.chamfer_forward(near, gt)
         torch.cuda.synchronize()
-    assert native._chamfer_policy.state[key]["brute_left"] == [0, 0]  # both directions keep sweeping
+    assert pol.state[key]["level"] == [0, 0]                          # both directions keep sweeping
+    # not sweep-eligible (2048 points): MFMA by default; a lattice (masses of exact ties) sends it to brute force
+    pol.state.clear()
+    lat = (torch.randint(0, 6, (4, 2048, 3), device="cuda").float() * 0.125 - 0.3)
+    lat2 = (torch.randint(0, 6, (4, 2048, 3), device="cuda").float() * 0.125 - 0.3)
+    want = native.chamfer_forward(lat, lat2, algorithm=native.CHAMFER_BRUTE)
+    used = []
+    for _ in range(6):
+        out = native.chamfer_forward(lat, lat2)
+        used.append(native.chamfer_algorithm_log[(4, 2048, 2048)])
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, want))
+    assert used[0] == (native.CHAMFER_MFMA, native.CHAMFER_MFMA) and used[-1] == (native.CHAMFER_BRUTE, native.CHAMFER_BRUTE), used
+    pol.state.clear()
 
 
 def test_chamfer_identity(native):
@@ -381,6 +417,37 @@ def test_packed_self_attention_and_linear_bias_grad(native):
     g4 = torch.randn(8192, 1536, device="cuda")
     assert (native.colsum(g4).double() - g4.double().sum(0)).abs().max().item() < 2e-3
     assert torch.equal(native.colsum(g3), native.colsum(g3))
+
+
+@pytest.mark.parametrize("B,M,C", [(32, 576, 1024), (1, 512, 1024), (2, 256, 384), (3, 7, 4), (2, 1, 8), (1, 33, 100)])
+def test_max_over_tokens_matches_torch(native, B, M, C):
+    """libptops' max over tokens (values bit-equal to torch.max(dim=1), gradient to the arg-max token, lowest token on
+    ties, NaN wins) — the memset-free replacement of ATen's strided reduction in the global-feature pools."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(B * 100 + M + C)
+    x = torch.randn(B, M, C, device="cuda")
+    x[0, M // 2, 0] = 100.0
+    if M > 2:
+        x[:, 1, 1] = 50.0
+        x[:, 2, 1] = 50.0                                        # exact tie: token 1 must take the gradient
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = TU.max_over_tokens(xa)
+    assert type(ya.grad_fn).__name__.startswith("_MaxTokensFn")
+    yb = torch.max(xb, dim=1)[0]
+    assert torch.equal(ya, yb)
+    g = torch.randn(B, C, device="cuda")
+    ya.backward(g)
+    assert torch.equal(xa.grad.sum(1), g) and int((xa.grad != 0).sum()) <= B * C
+    _, arg = native.max_tokens_forward(x)
+    assert torch.equal(torch.gather(x, 1, arg.long().unsqueeze(1)).squeeze(1), yb)
+    if M > 2:
+        assert bool((arg[:, 1] == 1).all())
+        assert torch.equal(xa.grad[:, 1, 1], g[:, 1]) and float(xa.grad[:, 2, 1].abs().max()) == 0.0
+    xn = x.clone()
+    xn[0, M - 1, 0] = float("nan")
+    out, _ = native.max_tokens_forward(xn)
+    assert bool(torch.isnan(out[0, 0])) and torch.equal(out[0, 1:], yb[0, 1:])
 
 
 def test_bias_gradient_handoff_ignores_other_layouts(native):
@@ -688,7 +755,7 @@ def test_padded_head_multihead_attention_equals_module(native, self_attention):
 
 def test_full_size_properties(native):
     """BASELINE sizes (B = 32, 2048 -> 16384), where the CPU oracle would take minutes: properties instead.
-    Chamfer: two independent algorithms (brute force, pruned sweep) agree bit for bit, the two directions are each
+    Chamfer: three independent algorithms (brute force, pruned sweep, MFMA filter) agree bit for bit, the two directions are each
     other's mirror, distances are invariant under a permutation of the target and the indices follow it, and the
     returned index reproduces the returned distance.  FPS: prefix property and first index.  kNN: the k-th distance
     equals torch.topk's on the reference's own expansion-form matrix up to its rounding, neighbours are sorted."""
@@ -699,6 +766,8 @@ def test_full_size_properties(native):
     brute = native.chamfer_forward(a, b, algorithm=native.CHAMFER_BRUTE)
     sweep = native.chamfer_forward(a, b, algorithm=native.CHAMFER_SWEEP)
     assert all(torch.equal(x, y) for x, y in zip(brute, sweep))
+    mfma = native.chamfer_forward(a, b, algorithm=native.CHAMFER_MFMA)
+    assert all(torch.equal(x, y) for x, y in zip(brute, mfma))
     d1, d2, i1, i2 = brute
     m1, m2, j1, j2 = native.chamfer_forward(b, a, algorithm=native.CHAMFER_BRUTE)
     assert torch.equal(d1, m2) and torch.equal(d2, m1) and torch.equal(i1, j2) and torch.equal(i2, j1)

@@ -62,6 +62,11 @@ def test_graphed_forward_matches_eager(native):
             want = model(x)
             got = gf(x)
             assert all(torch.equal(a, b) for a, b in zip(got, want)), i
+            # what validation does between two clouds: other kernels, allocations and a host synchronisation
+            # (metrics .item()).  A graph with a MEMSET node returns stale outputs after this (csrc/core.hip).
+            junk = torch.zeros(1000, device="cuda") + float(want[1].sum().item())
+            torch.cuda.synchronize()
+        assert gf.enabled and gf.disabled_reason is None      # the eval forward is graph-safe: no memset node in it
         assert gf.replays == 3
         xb = torch.rand(2, 2048, 3, device="cuda") - 0.5         # a second input signature gets its own graph
         assert all(torch.equal(a, b) for a, b in zip(gf(xb), model(xb)))
@@ -108,6 +113,18 @@ def test_graphed_forward_guards(native):
         def forward(self, x):
             self.calls += 1
             return x + self.calls
+
+    class StridedSum(torch.nn.Module):                            # ATen zeroes this reduction's semaphores with a memset
+        def forward(self, x):
+            return x.sum(dim=1)
+
+    gm = GraphedForward(StridedSum().cuda().eval())
+    with torch.no_grad():
+        for _ in range(3):
+            x = torch.randn(1, 512, 1024, device="cuda")
+            assert torch.equal(gm(x), x.sum(dim=1))               # right either way: graphed and sound, or refused
+            torch.cuda.synchronize()
+    assert gm.enabled or "host synchronisation" in gm.disabled_reason
 
     gd = GraphedForward(Stateful().cuda().eval())
     with torch.no_grad():
