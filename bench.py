@@ -9,10 +9,11 @@ A step = forward + get_loss (denoise kNN + 3 Chamfer) + backward + gradient aver
 clip_grad_norm_(10) + AdamW step on one batch of 32 clouds per GPU (2048-point partial ->
 16384-point completion; BASELINE.json configs[1]), fp32 throughout, inputs resident in HBM.
 Rank 0 prints ONE JSON line.  It carries
-  roofline     — the dominant hand-written kernel (Chamfer 16384x16384 nearest-neighbour search):
-                 algorithmic FLOPs / average launch duration measured with events on the launching
-                 stream during the timed steps, against the fp32 vector peak; plus the same launch
-                 priced in algorithmic HBM bytes;
+  roofline     — the Chamfer 16384x16384 nearest-neighbour launch (north_star's lead primitive): average launch
+                 duration measured with events on the launching stream during the timed steps; when the
+                 bf16x3 MFMA filter runs it, executed MFMA FLOPs against the dense bf16 peak (bound "mfma"),
+                 otherwise algorithmic FLOPs against the fp32 vector peak; plus the same launch priced in
+                 algorithmic FLOPs and algorithmic HBM bytes;
   cpu_baseline — the same train step run on the host cores through the CPU oracle ("port": the
                  reference has no CPU implementation of Chamfer / FPS), on a bounded sample.
 """
@@ -37,6 +38,7 @@ from imgadapointr_amd.utils.flat_ddp import FlatDDP  # noqa: E402
 from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (same table; 2:1 sparsity figures are not used)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add per squared distance
 N_PARTIAL, N_GT, BATCH = 2048, 16384, 32
@@ -77,31 +79,48 @@ class ChamferProbe:
         B = self.events[0][2]
         avg_ms = sum(ms) / len(ms)
         n, m = self.shape
-        flops = FLOP_PER_PAIR * 2.0 * B * n * m
-        achieved = flops / (avg_ms * 1e-3) / 1e12
+        pairs = 2.0 * B * n * m
+        alg_flops = FLOP_PER_PAIR * pairs
         alg_bytes = 20.0 * B * (n + m)
-        # HBM traffic and VALU activity of this launch come from separate rocprofv3 --pmc passes of the
-        # same kernel (cannot be collected from inside the timed run); their summary is committed.
+        algos = _native.chamfer_algorithm_log.get((B, n, m), (0, 0))
+        names = {0: "auto", 1: "brute-force chamfer_nn_kernel (VALU)", 2: "pruned sweep (VALU)",
+                 3: "bf16x3 MFMA filter + exact re-evaluation (chamfer_mfma_kernel)"}
+        on_mfma = all(a == _native.CHAMFER_MFMA for a in algos)
+        # HBM traffic and pipe activity of this launch come from separate rocprofv3 --pmc passes of the same kernel
+        # (cannot be collected from inside the timed run); their summary is committed.
+        pmc_name = "chamfer_mfma_pmc.json" if on_mfma else "chamfer_pmc.json"
+        pmc_file = os.path.join(ROOT, "profiles", "round2" if on_mfma else "round1", pmc_name)
         traffic, pmc = None, {}
-        pmc_file = os.path.join(ROOT, "profiles", "round1", "chamfer_pmc.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh).get("derived", {})
             traffic = pmc.get("hbm_traffic_bytes_corrected")
-        return {
-            "bound": "valu-fp32",
+        out = {
             "kernel": "Chamfer 16384x16384 forward launch (exact nearest neighbours, both directions; per direction the "
-                      "adaptive policy ran: " + "/".join({0: "auto", 1: "brute-force chamfer_nn_kernel", 2: "pruned sweep"}[a]
-                                                         for a in _native.chamfer_algorithm_log.get((B, n, m), (0, 0))) + ")",
-            "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": "profiles/round1/chamfer_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
-            "valu_busy_fraction_pmc": pmc.get("valu_busy_fraction"),
-            "launches": len(ms), "avg_launch_ms": round(avg_ms, 4),
-            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                      "adaptive policy ran: " + " / ".join(names[a] for a in algos) + ")",
+            "launches": len(ms), "avg_launch_ms": round(avg_ms, 4), "traffic": traffic,
+            "traffic_source": f"profiles/{'round2' if on_mfma else 'round1'}/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+            "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic": {"achieved": round(alg_flops / (avg_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                            "note": "8 FLOP per pair (3 sub, 3 mul, 2 add), every pair of both directions"},
             "hbm": {"achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)},
         }
+        if on_mfma:
+            # two v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs = 64 executed FLOP per pair (21 of the 32 k-slots carry
+            # piece products); the matrix pipe is the binding unit, the exact phase and the minima ride on the VALU
+            executed = 64.0 * pairs
+            achieved = executed / (avg_ms * 1e-3) / 1e12
+            out.update({"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "executed_flops_per_launch": executed,
+                        "mfma_busy_fraction_pmc": pmc.get("mfma_busy_fraction"),
+                        "clock_ghz_pmc": pmc.get("clock_ghz")})
+        else:
+            achieved = alg_flops / (avg_ms * 1e-3) / 1e12
+            out.update({"bound": "valu-fp32", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4),
+                        "valu_busy_fraction_pmc": pmc.get("valu_busy_fraction")})
+        return out
 
 
 class AttentionProbe:

@@ -169,7 +169,7 @@ def _same_device(*ts):
 
 # ------------------------------------------------------------------------------------------
 CHAMFER_AUTO, CHAMFER_BRUTE, CHAMFER_SWEEP, CHAMFER_MFMA = 0, 1, 2, 3
-CHAMFER_MFMA_MIN_CANDIDATES = 1024      # PTOPS_CHAMFER_MFMA_MIN_CANDIDATES of include/ptops.h
+CHAMFER_MFMA_MIN_PAIRS = 1 << 32        # PTOPS_CHAMFER_MFMA_MIN_PAIRS of include/ptops.h
 
 
 class _ChamferPolicy:
@@ -178,34 +178,35 @@ class _ChamferPolicy:
     * pruned sweep (both clouds 4096..16384 points): ~3x faster than brute force when nearest neighbours are close
       (trained predictions, well-spread clouds), useless when they are not (uniform queries against a prediction
       collapsed into a few clusters);
-    * MFMA filter (a direction that searches >= 1024 candidates): sees every pair on the matrix pipe, ~2x faster than
-      brute force whatever the geometry, unless masses of exactly tied distances (lattices, duplicated points) force
-      lanes into their exact scan;
+    * MFMA filter (launches of >= 2^32 pair evaluations, e.g. B = 32 at 16384 x 16384): sees every pair on the matrix
+      pipe, 2x faster than brute force whatever the geometry (0.95 vs 1.9 ms), unless masses of exactly tied distances
+      (lattices, duplicated points) force queries into their exact scan; below that size its prep pass and exact
+      phase cost more than they save;
     * brute force: the VALU kernel.
 
     Every swept / filtered direction accumulates {work done exactly, work a full scan would do} on the device; the
     counters are copied to pinned host memory without synchronising and looked at on a LATER call.  A sweep that still
-    evaluated more than `sweep_threshold` of the chunks is demoted to the MFMA filter, an MFMA filter that re-evaluated
+    evaluated more than `sweep_threshold` of the chunks is demoted to the next rung, an MFMA filter that re-evaluated
     more than `mfma_threshold` of the superblocks exactly is demoted to brute force, each for the next `hold` calls of
     the shape; then the preferred algorithm is probed again."""
     sweep_threshold = 0.35
-    mfma_threshold = 0.04
+    mfma_threshold = 0.03
     hold = 50
+    mfma_min_pairs = CHAMFER_MFMA_MIN_PAIRS
 
     def __init__(self):
         self.state = {}
 
-    @staticmethod
-    def _ladder(sweep_ok, n_candidates):
+    def _ladder(self, sweep_ok, pairs):
         ladder = [CHAMFER_SWEEP] if sweep_ok else []
-        if n_candidates >= CHAMFER_MFMA_MIN_CANDIDATES:
+        if pairs >= self.mfma_min_pairs:
             ladder.append(CHAMFER_MFMA)
         return ladder + [CHAMFER_BRUTE]
 
-    def choose(self, key, sweep_ok, n_candidates):
-        """-> ([algorithm of direction 0, of direction 1], state).  n_candidates = (m, n): what each direction searches."""
+    def choose(self, key, sweep_ok, pairs):
+        """-> ([algorithm of direction 0, of direction 1], state).  pairs = B * n * m, the pair evaluations of a direction."""
         st = self.state.setdefault(key, dict(level=[0, 0], left=[0, 0], pending=None))
-        ladders = [self._ladder(sweep_ok, n_candidates[d]) for d in range(2)]
+        ladders = [self._ladder(sweep_ok, pairs) for d in range(2)]
         pend = st["pending"]
         if pend is not None and pend[1].query():
             vals, used = pend[0].tolist(), pend[2]
@@ -271,7 +272,7 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
         stats = st = None
         if algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
             algos, st = _chamfer_policy.choose((dev.index, B, n, m), bool(lib.ptops_chamfer_sweep_available(B, n, m)),
-                                               (m, n))
+                                               B * n * m)
             if st["pending"] is None and any(a in (CHAMFER_SWEEP, CHAMFER_MFMA) for a in algos):
                 stats = torch.zeros(4, dtype=torch.int64, device=dev)
         _call("ptops_chamfer_forward_ex", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist1), _ptr(dist2),

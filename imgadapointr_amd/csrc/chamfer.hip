@@ -390,14 +390,14 @@ PTOPS_API int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int
   PTOPS_REQUIRE((long long)B * n * 3 < (1LL << 31) && (long long)B * m * 3 < (1LL << 31),
                 "chamfer_forward: B*n*3 must fit int32");
   const bool can_sweep = use_sweep(B, n, m);
-  const int nc[2] = {m, n};   // candidates searched by direction d
+  const long long pairs = (long long)B * n * m;   // pair evaluations of either direction
   int sweep_mask = 0, mfma_mask = 0;
   for (int d = 0; d < 2; ++d) {
     PTOPS_REQUIRE(algo[d] != PTOPS_CHAMFER_SWEEP || can_sweep,
                   "chamfer_forward: the sweep needs both clouds within [4096, 16384] points (n=%d m=%d)", n, m);
     if (algo[d] == PTOPS_CHAMFER_SWEEP || (algo[d] == PTOPS_CHAMFER_AUTO && can_sweep)) sweep_mask |= 1 << d;
     else if (algo[d] == PTOPS_CHAMFER_MFMA ||
-             (algo[d] == PTOPS_CHAMFER_AUTO && nc[d] >= PTOPS_CHAMFER_MFMA_MIN_CANDIDATES)) mfma_mask |= 1 << d;
+             (algo[d] == PTOPS_CHAMFER_AUTO && pairs >= PTOPS_CHAMFER_MFMA_MIN_PAIRS)) mfma_mask |= 1 << d;
   }
   // workspace layout: see ptops_chamfer_forward_workspace_bytes
   char* wsp = (char*)workspace;

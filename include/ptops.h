@@ -52,22 +52,23 @@ int ptops_chamfer_forward(const float* xyz1, const float* xyz2, int B, int n, in
  *   PTOPS_CHAMFER_BRUTE  every pair is evaluated (VALU-issue bound);
  *   PTOPS_CHAMFER_SWEEP  clouds are sorted by x and every query tile sweeps outwards until no farther
  *                        candidate can win or tie (exact pruning; needs ptops_chamfer_sweep_available);
- *   PTOPS_CHAMFER_MFMA   one v_mfma_f32_16x16x4_f32 per 16 x 16 pairs evaluates |c|^2 - 2 c.q as a FILTER with a
- *                        proven error bound; the one or two 64-candidate superblocks per lane that can hold the
- *                        nearest neighbour are re-evaluated with the exact direct-difference arithmetic (every pair
- *                        is seen, the vector pipe only keeps minima; matrix-pipe bound);
- *   PTOPS_CHAMFER_AUTO   the sweep whenever it is available, else the MFMA filter for directions that search at
- *                        least PTOPS_CHAMFER_MFMA_MIN_CANDIDATES points, else brute force.
+ *   PTOPS_CHAMFER_MFMA   the matrix pipe searches, the vector pipe only keeps minima: coordinates are split into three
+ *                        bf16 pieces and two v_mfma_f32_32x32x16_bf16 evaluate |c|^2 - 2 c.q for 32 x 32 pairs as a
+ *                        FILTER with a proven error bound; per query only the one or two 128-candidate superblocks that
+ *                        can hold the nearest neighbour are re-evaluated with the exact direct-difference arithmetic
+ *                        (every pair is seen; about twice the speed of brute force on large clouds whatever the
+ *                        geometry; masses of exactly tied distances make it slower);
+ *   PTOPS_CHAMFER_AUTO   the sweep whenever it is available, else the MFMA filter for directions with at least
+ *                        PTOPS_CHAMFER_MFMA_MIN_PAIRS pair evaluations (B * queries * candidates), else brute force.
  * stats (optional, 4 x u64, device memory, caller-zeroed): a swept direction d adds {16-candidate chunks
  * evaluated, chunks a brute force would evaluate} to stats[2d], stats[2d+1]; an MFMA-filtered direction adds
- * {64-candidate superblocks re-evaluated exactly beyond the one every lane needs, superblocks visited} (per lane), so
- * that a caller can steer the
- * choice for the following calls. */
+ * {128-candidate superblocks re-evaluated exactly beyond the one every query needs, superblocks visited} (per lane), so
+ * that a caller can steer the choice for the following calls. */
 #define PTOPS_CHAMFER_AUTO 0
 #define PTOPS_CHAMFER_BRUTE 1
 #define PTOPS_CHAMFER_SWEEP 2
 #define PTOPS_CHAMFER_MFMA 3
-#define PTOPS_CHAMFER_MFMA_MIN_CANDIDATES 1024
+#define PTOPS_CHAMFER_MFMA_MIN_PAIRS (1LL << 32)
 int ptops_chamfer_sweep_available(int B, int n, int m);
 int ptops_chamfer_forward_ex(const float* xyz1, const float* xyz2, int B, int n, int m,
                              float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,

@@ -26,21 +26,21 @@ def test_library_exports_every_declared_symbol():
 def test_workspace_query_is_pure_host_code():
     from imgadapointr_amd import _native
     lib = _native.load()
-    # [sweep: sorted float4 copies of both clouds | MFMA filter: float4 operands of both clouds, 2 x B bounds,
+    # [sweep: sorted float4 copies of both clouds | MFMA filter: bf16 operand tiles of both clouds,
     #  packed minima | brute force: packed minima when it splits its candidates], each part rounded up to 256 bytes
     def a256(v):
         return (v + 255) // 256 * 256
 
-    def mfma(B, n, m):
-        p64 = lambda k: (k + 63) // 64 * 64
-        return a256(a256(16 * B * p64(n)) + a256(16 * B * p64(m)) + a256(8 * B) + 8 * B * (n + m))
+    def mfma(B, n, m):      # 48 bytes of bf16 operand pieces per candidate, candidates padded to 256-point superblocks
+        pad = lambda k: (k + 255) // 256 * 256
+        return a256(a256(48 * B * pad(n)) + a256(48 * B * pad(m)) + 8 * B * (n + m))
 
     assert lib.ptops_chamfer_sweep_available(32, 16384, 16384) == 1
     assert lib.ptops_chamfer_forward_workspace_bytes(32, 16384, 16384) == \
         16 * 32 * 32768 + mfma(32, 16384, 16384) + 8 * 32 * 32768
     assert lib.ptops_chamfer_sweep_available(32, 512, 16384) == 0
     assert lib.ptops_chamfer_forward_workspace_bytes(32, 512, 16384) == mfma(32, 512, 16384) + 8 * 32 * (512 + 16384)
-    assert lib.ptops_chamfer_forward_workspace_bytes(1, 100, 77) == mfma(1, 100, 77)      # ragged sizes pad to 64
+    assert lib.ptops_chamfer_forward_workspace_bytes(1, 100, 77) == mfma(1, 100, 77)      # ragged sizes pad to 256
     assert lib.ptops_chamfer_forward_workspace_bytes(0, 10, 10) == 0
 
 

@@ -100,12 +100,13 @@ def test_chamfer_mfma_filter_error_bound(native, ref, kind, scale, shift):
         assert np.array_equal(g.cpu().numpy().view(np.uint32), w.view(np.uint32)), (kind, scale, shift)
 
 
-def test_chamfer_adaptive_policy(native):
+def test_chamfer_adaptive_policy(native, monkeypatch):
     """The adaptive choice never changes results; a direction whose sweep cannot prune is demoted to the MFMA filter,
     and an MFMA filter drowning in exact ties is demoted to brute force."""
     key = (0, 4, 8192, 8192)
     pol = native._chamfer_policy
     pol.state.clear()
+    monkeypatch.setattr(pol, "mfma_min_pairs", 0)                     # small clouds here: let the MFMA rung take part
     gt = torch.rand(4, 8192, 3, device="cuda") - 0.5
     blob = (torch.randn(4, 8192, 3, device="cuda") * 1e-3)           # the whole cloud in one tiny cluster
     ref_out = native.chamfer_forward(blob, gt, algorithm=native.CHAMFER_BRUTE)
