@@ -59,6 +59,8 @@ def _declare(lib):
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+        "ptops_gemm_f32_split3": (c_int, [P, ctypes.c_longlong, c_int, P, ctypes.c_longlong, c_int, P, ctypes.c_longlong,
+                                          c_int, c_int, c_int, P, P]),
         "ptops_max_tokens_backward": (c_int, [P, P, c_int, c_int, c_int, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
         "ptops_layer_norm_max_dim": (c_int, []),
@@ -91,7 +93,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
-    "ptops_max_tokens_forward", "ptops_max_tokens_backward",
+    "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
@@ -625,6 +627,29 @@ def max_tokens_backward(grad_out, arg, M):
         gx = torch.empty((B, int(M), C), dtype=torch.float32, device=grad_out.device)
         _call("ptops_max_tokens_backward", _ptr(grad_out), _ptr(arg), B, int(M), C, _ptr(gx), _stream(grad_out))
     return gx
+
+
+def gemm_split3(a, b, bias=None, a_k_contiguous=True, b_k_contiguous=True, out=None):
+    """fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split3.hip): out[M,N] = A . B^T (+ bias).
+
+    a: [M,K] if a_k_contiguous else [K,M]; b: [N,K] if b_k_contiguous else [K,N]; both fp32 2-D with unit inner stride
+    (row strides are passed on, so row-sliced views work).  K % 16 == 0."""
+    for name, t in (("a", a), ("b", b)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise ValueError(f"gemm_split3: {name} must be a 2-D fp32 CUDA tensor with unit inner stride")
+    _same_device(a, b)
+    M, K = (a.shape[0], a.shape[1]) if a_k_contiguous else (a.shape[1], a.shape[0])
+    N, K2 = (b.shape[0], b.shape[1]) if b_k_contiguous else (b.shape[1], b.shape[0])
+    if K != K2:
+        raise ValueError(f"gemm_split3: inner sizes differ ({K} vs {K2})")
+    with torch.cuda.device(a.device):
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if bias is not None:
+            _check(bias, "bias", torch.float32, 1)
+        _call("ptops_gemm_f32_split3", _ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous),
+              _ptr(out), out.stride(0), M, N, K, _ptr(bias) if bias is not None else None, _stream(a))
+    return out
 
 
 def _scratch(dev, stream, need):

@@ -1,0 +1,202 @@
+// fp32 GEMM on the bf16 matrix pipe: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), fp32 in, fp32 out, gfx950 (MI355X).
+//
+// The dense layers of the path (models/Transformer_utils.py:71-159 of the reference: nn.Linear forward and backward)
+// are fp32 GEMMs; gfx950 has no TF32-like mode and its f32 MFMA runs at the f32 vector rate (157 TFLOP/s), where the
+// library kernels already sit at 70-90 %.  The bf16 MFMA is 16x faster, so each f32 operand is split in the kernel into
+// three bf16 pieces, x = h + m + l (round to nearest; exact to 2^-27 |x|), and every k-step issues the six piece
+// products down to 2^-18: Ah.Bh, Ah.Bm, Am.Bh, Ah.Bl, Am.Bm, Al.Bh.  bf16 x bf16 products are exact in f32 and the
+// MFMA accumulates in f32 (measured in chamfer_mfma.hip: like a single-rounding f32 sum), the dropped products are
+// <= 3 * 2^-26 |a||b| per term: the result is as close to the exact product as an f32 FMA chain is (tests compare both
+// with float64).  6 MFMA per k-step at 16x the rate = 2.7x the f32 matrix peak at equal clocks.
+//
+// Tiling: 128 x 128 output tile per workgroup (8 waves, 32 x 64 each = 1 x 2 MFMA blocks of 32 x 32), k-step 16.
+// Staging: every thread loads the 8 f32 of ONE operand entry (row, k-half), splits them and writes the three 16-byte
+// bf16 entries to LDS ([piece][k-half][row], conflict-free ds_read_b128); the next k-step's loads are in flight while
+// the current one computes; double-buffered LDS, one barrier per k-step.  Either operand may be stored with k
+// contiguous ([rows, ld]) or with k strided ([K, ld], rows contiguous): the strided form reads 8 coalesced dwords
+// instead of two dwordx4, so A.B^T (forward), A.B (input gradient) and A^T.B (weight gradient) use one kernel.
+#include "ptops_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 16;
+// entries per k-half plane: 128 rows + 4 of padding, so that the 8 lanes of a ds_write_b128 group (rows r .. r+3 of both
+// k-halves when k is contiguous) fall on 8 different 16-byte bank groups; reads stay consecutive within a half
+constexpr int kPlane = 132;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;   // [N] or null
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int tiles_n;
+};
+
+struct Pieces {
+  uint4 h, m, l;
+};
+
+// 8 f32 -> three 8 x bf16 entries
+__device__ __forceinline__ Pieces split8(const float (&x)[8]) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    h[i] = a;
+    m[i] = b;
+    l[i] = c;
+  }
+  Pieces p;
+  p.h = __builtin_bit_cast(uint4, h);
+  p.m = __builtin_bit_cast(uint4, m);
+  p.l = __builtin_bit_cast(uint4, l);
+  return p;
+}
+
+// One operand entry of the tile that starts at row r0 / k-step k0: 8 consecutive k of one row.
+//   KC (k contiguous, [rows, ld]): thread t -> row t >> 1, k-half t & 1
+//   else (k strided,  [K, ld])   : thread t -> row t & 127, k-half t >> 7
+template <bool KC>
+__device__ __forceinline__ void load_entry(const float* __restrict__ P, long long ld, int rows, int r0, int k0, int t,
+                                           float (&x)[8]) {
+  if (KC) {
+    const int row = min(r0 + (t >> 1), rows - 1);
+    const float4* p = reinterpret_cast<const float4*>(P + (long long)row * ld + k0 + 8 * (t & 1));
+    const float4 u = p[0], v = p[1];
+    x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = v.x, x[5] = v.y, x[6] = v.z, x[7] = v.w;
+  } else {
+    const int row = min(r0 + (t & 127), rows - 1);
+    const float* p = P + (long long)(k0 + 8 * (t >> 7)) * ld + row;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = p[(long long)i * ld];
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ int entry_index(int t) {
+  return KC ? ((t & 1) * kPlane + (t >> 1)) : ((t >> 7) * kPlane + (t & 127));
+}
+
+// 8 waves per 128 x 128 tile: wave w owns rows (w >> 1) * 32 .. + 31 and columns (w & 1) * 64 .. + 63 (two MFMA blocks).
+// Thread t < 256 stages A entry t, thread t >= 256 stages B entry t - 256 (one entry = 8 f32 of one row -> 3 x 16 bytes).
+// With 4 waves per tile and 432 tiles (M = 18432, N = 384) a SIMD mostly hosts ONE wave, whose LDS / staging / barrier
+// phases leave the matrix pipe idle; 8 waves put two waves of every tile on each SIMD (107 -> ? TFLOP/s).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
+  // [buffer][operand][piece][k-half * kPlane + row]
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give every XCD one contiguous range of tiles, so that
+  // the tiles_n tiles that read the same 128 rows of A do so through one L2 (bijective for any grid; speed only).
+  int bid;
+  {
+    const int orig = blockIdx.x, nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
+  const int m0 = tile_m * kBM, n0 = tile_n * kBN;
+  const bool stage_b = t >= 256;
+  const int tt = t & 255;
+  const int e = stage_b ? entry_index<BKC>(tt) : entry_index<AKC>(tt);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float x[8];
+  auto load = [&](int k0) {
+    if (stage_b) load_entry<BKC>(g.B, g.ldb, g.N, n0, k0, tt, x);
+    else load_entry<AKC>(g.A, g.lda, g.M, m0, k0, tt, x);
+  };
+  auto store = [&](int buf) {
+    const Pieces p = split8(x);
+    uint4(*dst)[2 * kPlane] = lds[buf][stage_b ? 1 : 0];
+    dst[0][e] = p.h, dst[1][e] = p.m, dst[2][e] = p.l;
+  };
+  load(0);
+  store(0);
+  __syncthreads();
+
+  // (Tried: waves w and w + 4 — SIMD partners — staggered, one splitting / storing the next k-step before its MFMAs
+  // and one after, with loads two k-steps ahead: 112 VGPRs instead of 79 and 3-30 % slower.)
+  const int ksteps = g.K / kBK;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < ksteps;
+    if (more) load((ks + 1) * kBK);          // next k-step: global -> registers now, split + LDS after the math
+    bf16x8 a[3], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a[p] = __builtin_bit_cast(bf16x8, lds[cur][0][p][half * kPlane + wr * 32 + col]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[p][j] = __builtin_bit_cast(bf16x8, lds[cur][1][p][half * kPlane + wc * 64 + j * 32 + col]);
+    }
+    // six piece products per block, smallest first; the two blocks alternate so that no MFMA waits on the one before
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      // (piece of A, piece of B): (l,h) (m,m) (h,l) (m,h) (h,m) (h,h)
+      const int pa = term == 0 ? 2 : ((term == 1 || term == 3) ? 1 : 0);
+      const int pb = term == 2 ? 2 : ((term == 1 || term == 4) ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb][j], acc[j], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: block j register r holds C[m0 + wr*32 + (r&3) + 8 (r>>2) + 4 half][n0 + wc*64 + j*32 + col]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 64 + j * 32 + col;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < g.M) g.C[(long long)m * g.ldc + n] = acc[j][r] + bv;
+    }
+  }
+}
+
+}  // namespace
+
+// C[M,N] = opA . opB^T + bias.  a_k_contiguous: A is stored [M, lda] (k contiguous) else [K, lda] (m contiguous);
+// b_k_contiguous: B is stored [N, ldb] else [K, ldb].  K % 16 == 0; a k-contiguous operand needs 16-byte aligned rows.
+PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
+                                    int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_split3: negative size");
+  if (M == 0 || N == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(A && B && C, "gemm_f32_split3: null pointer");
+  PTOPS_REQUIRE(K >= 16 && K % 16 == 0, "gemm_f32_split3: K must be a positive multiple of 16 (K=%d)", K);
+  if (a_k_contiguous) PTOPS_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0, "gemm_f32_split3: A rows must be 16-byte aligned");
+  if (b_k_contiguous) PTOPS_REQUIRE(ldb % 4 == 0 && ((uintptr_t)B & 15) == 0, "gemm_f32_split3: B rows must be 16-byte aligned");
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = bias;
+  g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_n = ptops::ceil_div(N, kBN);
+  const long long blocks = (long long)ptops::ceil_div(M, kBM) * g.tiles_n;
+  PTOPS_REQUIRE(blocks < (1LL << 31), "gemm_f32_split3: grid too large");
+  dim3 grid((unsigned)blocks), block(512);
+  if (a_k_contiguous && b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, block, 0, stream, g);
+  else if (a_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, block, 0, stream, g);
+  else if (b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, block, 0, stream, g);
+  return ptops::check_launch("gemm_split3_kernel");
+}

@@ -11,6 +11,8 @@ kNN, the gathers, head-dim-64 attention (forward and backward), LayerNorm (+ fus
 and the bias-gradient column sums run on libptops (csrc/knn.hip, gather.hip, attention.hip, layernorm.hip,
 activation.hip, reduce.hip); the dense GEMMs stay on PyTorch-ROCm (hipBLASLt / rocBLAS MFMA kernels).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -58,14 +60,51 @@ def linear_on_broadcast_concat(lin, g, x):
     return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
 
 
+# Dense layers on libptops' fp32-on-bf16-matrix-pipe GEMM (csrc/gemm_split3.hip: operands split into three bf16 pieces,
+# six exact piece products accumulated in fp32 — as accurate as an fp32 FMA chain, see tests) where it beats the fp32
+# MFMA library kernels: large row counts (benchmarks/gemm_split3_probe.py, profiles/round2/gemm_split3_probe_*.log).
+# PTOPS_SPLIT3_GEMM=0 keeps every GEMM on hipBLASLt / rocBLAS.
+USE_SPLIT3_GEMM = os.environ.get("PTOPS_SPLIT3_GEMM", "1") != "0"
+
+
+def _split3_ok(a, k):
+    return (USE_SPLIT3_GEMM and a.is_cuda and a.dtype == torch.float32 and k % 16 == 0 and a.dim() == 2
+            and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+            and _native.backend_for_testing() is None)
+
+
+def _use_split3_forward(x2, weight):
+    M, K = x2.shape
+    N = weight.size(0)
+    return (_split3_ok(x2, K) and _split3_ok(weight, K) and N >= 128 and (M >= 16384 or (M >= 8192 and N >= 768)))
+
+
+def _use_split3_dgrad(g2, weight):
+    M, N = g2.shape                     # contraction over N (out_features), output width K (in_features)
+    K = weight.size(1)
+    return (_split3_ok(g2, N) and weight.is_cuda and weight.dtype == torch.float32 and weight.stride(1) == 1
+            and K >= 128 and M >= 16384 and (N >= 512 or K >= 1024))
+
+
+def linear_forward(x, weight, bias):
+    """F.linear(x, weight, bias), on the split-bf16 GEMM where that is the faster fp32-accurate kernel."""
+    K = x.size(-1)
+    if x.is_cuda and x.dim() >= 2 and x.is_contiguous():
+        x2 = x.view(-1, K)
+        if _use_split3_forward(x2, weight):
+            return _native.gemm_split3(x2, weight, bias).view(*x.shape[:-1], weight.size(0))
+    return F.linear(x, weight, bias)
+
+
 class _LinearFn(torch.autograd.Function):
     """F.linear whose bias gradient is libptops' streaming column sum (csrc/reduce.hip) instead of the
-    generic 2-5 workgroup reduction autograd would run; the three GEMMs are the ones autograd runs."""
+    generic 2-5 workgroup reduction autograd would run; forward and input-gradient GEMMs go to the split-bf16 kernel
+    where it wins, the weight gradient stays on the library's split-K kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        return F.linear(x, weight, bias)
+        return linear_forward(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad):
@@ -73,7 +112,10 @@ class _LinearFn(torch.autograd.Function):
         g2 = grad.reshape(-1, grad.size(-1))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ weight).view(x.shape)
+            if g2.is_contiguous() and _use_split3_dgrad(g2, weight):
+                gx = _native.gemm_split3(g2, weight, None, True, False).view(x.shape)
+            else:
+                gx = (g2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             gw = g2.t() @ x.reshape(-1, x.size(-1))
         if ctx.needs_input_grad[2]:
@@ -123,6 +165,8 @@ class Linear(nn.Linear):
                 and self.out_features % 4 == 0 and torch.is_grad_enabled() and x.dim() >= 2
                 and x.numel() // x.size(-1) >= 2048 and _native.backend_for_testing() is None):
             return _LinearFn.apply(x, self.weight, self.bias)
+        if not torch.is_grad_enabled():
+            return linear_forward(x, self.weight, self.bias)      # validation / inference: same kernels as training
         return F.linear(x, self.weight, self.bias)
 
 

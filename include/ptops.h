@@ -303,6 +303,17 @@ int ptops_max_tokens_forward(const float* x, int B, int M, int C, float* out, in
 int ptops_max_tokens_backward(const float* grad_out, const int32_t* arg, int B, int M, int C, float* grad_x,
                               void* stream);
 
+/* ------------------------------------------------- fp32 GEMM on the bf16 matrix pipe --
+ * C[M,N] = A . B^T (+ bias[N]) for fp32 operands, the product every nn.Linear of the path evaluates forward and
+ * backward (models/Transformer_utils.py:71-159).  Each operand is split in the kernel into three bf16 pieces and the
+ * six piece products down to 2^-18 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: as accurate as an fp32 FMA
+ * chain, 2.7x the fp32 matrix peak.  A is logically [M,K], B logically [N,K]; either may be stored with k contiguous
+ * ([rows, ld], *_k_contiguous = 1) or with k strided ([K, ld], rows contiguous, = 0), which covers x.W^T (forward),
+ * dy.W (input gradient) and dy^T.x (weight gradient).  K % 16 == 0; k-contiguous operands need 16-byte aligned rows. */
+int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
+                          int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -451,6 +451,66 @@ def test_max_over_tokens_matches_torch(native, B, M, C):
     assert bool(torch.isnan(out[0, 0])) and torch.equal(out[0, 1:], yb[0, 1:])
 
 
+@pytest.mark.parametrize("M,N,K", [(18432, 384, 384), (16384, 1152, 384), (8192, 768, 1024), (300, 96, 64), (129, 130, 16),
+                                   (4097, 1027, 48)])
+def test_gemm_split3_is_fp32_accurate(native, M, N, K):
+    """fp32 GEMM on the bf16 matrix pipe (three bf16 pieces per operand, six exact piece products, fp32 accumulation):
+    its error against float64 must not exceed that of the library's fp32 MFMA GEMM (same order: both are bounded by
+    the fp32 accumulation), in all three operand layouts (x.W^T, dy.W, dy^T.x) and on ragged tiles."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda") * torch.logspace(-3, 3, K, device="cuda")      # columns of very different size
+    w = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    dy = torch.randn(M, N, device="cuda")
+    rows = slice(0, min(M, 1024))
+
+    def rel(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    ref = x[rows].double() @ w.double().t() + b.double()
+    got = native.gemm_split3(x, w, b)
+    lib = torch.nn.functional.linear(x, w, b)
+    assert rel(got[rows], ref) <= max(2.0 * rel(lib[rows], ref), 2e-6), (rel(got[rows], ref), rel(lib[rows], ref))
+    ref = dy[rows].double() @ w.double()
+    got = native.gemm_split3(dy, w, None, True, False) if N % 16 == 0 else None
+    if got is not None:
+        assert rel(got[rows], ref) <= max(2.0 * rel((dy @ w)[rows], ref), 2e-6)
+    if M % 16 == 0:
+        ref = dy.double().t() @ x.double()
+        got = native.gemm_split3(dy, x, None, False, False)
+        assert rel(got, ref) <= max(4.0 * rel(dy.t() @ x, ref), 1e-5)
+    # row-sliced views (row stride != row length) and the alignment check
+    xv = torch.randn(M, K + 16, device="cuda")[:, :K]
+    assert rel(native.gemm_split3(xv, w)[rows], xv[rows].double() @ w.double().t()) < 5e-6
+    with pytest.raises(native.PtopsError):
+        native.gemm_split3(torch.randn(M, 20, device="cuda")[:, 1:17], w[:, :16])      # rows start 4 bytes off a 16-byte boundary
+
+
+def test_linear_layers_on_split3_match_library(native):
+    """nn.Linear-compatible module: forward, input gradient, weight gradient and bias gradient with the split-bf16 GEMM
+    switched on and off agree to fp32 accuracy (the weight gradient is the library's either way)."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(21)
+    lin = TU.Linear(384, 1152).cuda()
+    x = torch.randn(32, 576, 384, device="cuda", requires_grad=True)
+    g = torch.randn(32, 576, 1152, device="cuda")
+    res = {}
+    for on in (True, False):
+        TU.USE_SPLIT3_GEMM = on
+        lin.zero_grad()
+        y = lin(x)
+        gx, = torch.autograd.grad(y, x, g, retain_graph=True)
+        y.backward(g)
+        res[on] = (y.detach(), gx, lin.weight.grad.clone(), lin.bias.grad.clone())
+    TU.USE_SPLIT3_GEMM = True
+    ref_y = x.detach().double() @ lin.weight.detach().double().t() + lin.bias.detach().double()
+    ref_gx = g.double() @ lin.weight.detach().double()
+    for a, bq, ref in ((res[True][0], res[False][0], ref_y), (res[True][1], res[False][1], ref_gx)):
+        ea, eb = float((a.double() - ref).abs().max()), float((bq.double() - ref).abs().max())
+        assert ea <= max(2.0 * eb, 1e-6 * float(ref.abs().max())), (ea, eb)
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+
+
 def test_bias_gradient_handoff_ignores_other_layouts(native):
     """Column sums a producer kernel offers for a gradient tensor are taken only for that very layout.
     A transposed view of a square gradient has the same address and shape but other strides; an in-place write after
