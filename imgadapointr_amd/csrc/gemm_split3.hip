@@ -133,6 +133,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
 
   // (Tried: waves w and w + 4 — SIMD partners — staggered, one splitting / storing the next k-step before its MFMAs
   // and one after, with loads two k-steps ahead: 112 VGPRs instead of 79 and 3-30 % slower.)
+  // Tried on this loop, none faster (profiles/round2/gemm_split3_notes.txt): global loads two k-steps ahead with a raw
+  // s_barrier so that they stay in flight (0-8 % slower: 9 more VGPRs, 8 v_mov per step); SIMD partners (waves w, w + 4)
+  // staggered, one splitting / storing before its MFMAs and one after (3-30 % slower); 4 waves of 64 x 64 (10 % slower:
+  // one wave per SIMD on most CUs at 432 tiles).
   const int ksteps = g.K / kBK;
   for (int ks = 0; ks < ksteps; ++ks) {
     const int cur = ks & 1;
