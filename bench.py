@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from imgadapointr_amd import _native  # noqa: E402
 from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
+from imgadapointr_amd.models import Transformer_utils as TU  # noqa: E402
 from imgadapointr_amd.tools import builder  # noqa: E402
 from imgadapointr_amd.tools.runner import TrainStep  # noqa: E402
 from imgadapointr_amd.utils.config import cfg_from_yaml_file  # noqa: E402
@@ -376,6 +377,12 @@ def main():
             "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
                                    f"bs={B}/GPU, full train step (BASELINE configs[1])",
                        "global_batch": world * B, "parallelism": f"dp{world}", "gemm_selection": gemm,
+                       "gemm_arithmetic": ("fp32 in / fp32 out everywhere; Linear forward + input-gradient GEMMs with >= 16384 rows "
+                                           "run on libptops' split-bf16 kernel (three bf16 pieces per operand, six exact piece "
+                                           "products, fp32 accumulation: error vs float64 <= the fp32 MFMA library kernels, "
+                                           "tests/test_kernels_gpu.py::test_gemm_split3_is_fp32_accurate); PTOPS_SPLIT3_GEMM=0 "
+                                           "keeps all GEMMs on hipBLASLt / rocBLAS fp32 MFMA (+0.8 ms per step)")
+                       if TU.USE_SPLIT3_GEMM else "fp32 MFMA library kernels (hipBLASLt / rocBLAS) for every GEMM",
                        "params": sum(p.numel() for p in model.parameters())},
             "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
             "roofline": probe.summary(),
