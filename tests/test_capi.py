@@ -66,3 +66,44 @@ def test_oracle_is_not_imported_by_the_package():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libptops_ref" not in src, fn
+
+
+def test_chamfer_policy_ladder_on_cpu():
+    """Host logic of the adaptive Chamfer choice (_native._ChamferPolicy): sweep -> MFMA filter -> brute force, demoted by
+    the device counters of an EARLIER call, re-probed after `hold` calls.  No GPU: the pending read-back is faked."""
+    from imgadapointr_amd import _native as nat
+
+    class Done:
+        def query(self):
+            return True
+
+    class Stats:
+        def __init__(self, vals):
+            self.vals = vals
+
+        def tolist(self):
+            return self.vals
+
+    pol = nat._ChamferPolicy()
+    big = 1 << 33
+    # sweep-eligible, large: starts with the sweep in both directions
+    algos, st = pol.choose("k", True, big)
+    assert algos == [nat.CHAMFER_SWEEP, nat.CHAMFER_SWEEP]
+    # direction 1 evaluated 90 % of its chunks: demoted to the MFMA filter, direction 0 (5 %) keeps sweeping
+    st["pending"] = (Stats([5, 100, 90, 100]), Done(), tuple(algos))
+    algos, st = pol.choose("k", True, big)
+    assert algos == [nat.CHAMFER_SWEEP, nat.CHAMFER_MFMA] and st["left"][1] == pol.hold - 1
+    # the filter drowns in exact ties (10 % of the superblocks re-evaluated): down to brute force
+    st["pending"] = (Stats([0, 0, 10, 100]), Done(), tuple(algos))
+    algos, st = pol.choose("k", True, big)
+    assert algos == [nat.CHAMFER_SWEEP, nat.CHAMFER_BRUTE]
+    for _ in range(pol.hold):                       # after `hold` calls the preferred algorithm is probed again
+        algos, st = pol.choose("k", True, big)
+    assert algos == [nat.CHAMFER_SWEEP, nat.CHAMFER_SWEEP]
+    # small launches never use the filter; without the sweep the ladder is MFMA -> brute or just brute
+    assert pol.choose("s", False, 1 << 20)[0] == [nat.CHAMFER_BRUTE, nat.CHAMFER_BRUTE]
+    assert pol.choose("m", False, big)[0] == [nat.CHAMFER_MFMA, nat.CHAMFER_MFMA]
+    assert pol.choose("t", True, 1 << 28)[0] == [nat.CHAMFER_SWEEP, nat.CHAMFER_SWEEP]
+    _, st = pol.choose("t", True, 1 << 28)
+    st["pending"] = (Stats([80, 100, 80, 100]), Done(), (nat.CHAMFER_SWEEP, nat.CHAMFER_SWEEP))
+    assert pol.choose("t", True, 1 << 28)[0] == [nat.CHAMFER_BRUTE, nat.CHAMFER_BRUTE]
