@@ -190,6 +190,192 @@ __global__ __launch_bounds__(W * 64, 3) void attn_fwd_kernel(AttnArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Forward on the bf16 matrix pipe with fp32 accuracy (round 2).  Same algorithm, tiling and outputs as attn_fwd_kernel;
+// every fp32 operand is split into three bf16 pieces (x = h + m + l, exact to 2^-27) and each contraction issues the six
+// piece products down to 2^-18 on v_mfma_f32_32x32x16_bf16 (see csrc/gemm_split3.hip for the arithmetic argument):
+// 48 MFMAs of 32 cycles per 32 x 32 tile instead of 64 of 64 cycles.
+//   S^T = K Q^T : A = K pieces from LDS ([piece][16-dim chunk][k-half][key], rows padded to 33 entries), B = Q pieces
+//                 (pre-scaled, split once, 48 VGPRs);
+//   O^T = V^T P : B = the P pieces, split on the fly from the S^T accumulator: k-step s takes registers 8s..8s+7, whose
+//                 element jj of lane half h is key 16s + 8 (jj >> 2) + 4h + (jj & 3); A = V^T pieces from LDS, staged in
+//                 exactly that key order ([piece][k-step][k-half][dim]).
+// K and V are split by the 256 staging threads (one 8-value operand entry each) on their way into LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Pieces3 {
+  uint4 h, m, l;
+};
+
+__device__ __forceinline__ Pieces3 split8(const float (&x)[8]) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    h[i] = a;
+    m[i] = b;
+    l[i] = c;
+  }
+  Pieces3 p;
+  p.h = __builtin_bit_cast(uint4, h);
+  p.m = __builtin_bit_cast(uint4, m);
+  p.l = __builtin_bit_cast(uint4, l);
+  return p;
+}
+
+// the six piece products, smallest first: (piece of A, piece of B)
+#define PTOPS_SPLIT3_TERMS(F) F(2, 0) F(1, 1) F(0, 2) F(1, 0) F(0, 1) F(0, 0)
+
+__global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
+  constexpr int W = 4;
+  constexpr int kKRow = 33;                                  // padded: conflict-free ds_write_b128 of 8 lanes per key
+  __shared__ uint4 sK[2][3 * 4 * 2][kKRow];                  // [buf][(piece*4 + chunk)*2 + half][key]
+  __shared__ uint4 sV[2][3 * 2 * 2][64];                     // [buf][(piece*2 + kstep)*2 + half][dim]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int q0 = (blockIdx.x * W + wave) * 32;
+  const bool active = q0 < a.Nq;  // wave-uniform
+  const float* qb = a.q + b * a.q_sb + head * a.q_sh;
+  const float* kb = a.k + b * a.k_sb + head * a.k_sh;
+  const float* vb = a.v + b * a.v_sb + head * a.v_sh;
+
+  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
+  const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
+  const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
+
+  // B operands of S^T = K Q^T: lane (j,h), chunk c holds Q[q0+j][16c + 8h + 0..7], pre-scaled, as three pieces
+  bf16x8 bq[3][4];
+  {
+    const float* qp = qb + (long long)(active ? q0 + j : 0) * a.q_sn + 8 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x[8];
+      const f32x4 u = *reinterpret_cast<const f32x4*>(qp + 16 * c), w = *reinterpret_cast<const f32x4*>(qp + 16 * c + 4);
+      x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = w.x, x[5] = w.y, x[6] = w.z, x[7] = w.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = active ? x[i] * a.scale_log2e : 0.0f;
+      const Pieces3 p = split8(x);
+      bq[0][c] = __builtin_bit_cast(bf16x8, p.h);
+      bq[1][c] = __builtin_bit_cast(bf16x8, p.m);
+      bq[2][c] = __builtin_bit_cast(bf16x8, p.l);
+    }
+  }
+
+  f32x16 o0 = {0}, o1 = {0};  // O^T accumulators: dims 0..31 and 32..63, query on the lane
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  // staging: thread e owns one K entry (key e >> 3, dims 8 (e & 7) ..) and one V entry (dim e & 63, k-step / half e >> 6)
+  const int k_row = tid >> 3, k_oct = tid & 7;
+  const int k_slot = (k_oct >> 1) * 2 + (k_oct & 1);          // chunk * 2 + half
+  const int v_dim = tid & 63, v_sh = tid >> 6;                  // v_sh = kstep * 2 + half
+  float kx[8], vx[8];
+  auto fetch_tile = [&](int key0) {
+    const float* kp = kb + (long long)(key0 + k_row) * a.k_sn + 8 * k_oct;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(kp), w = *reinterpret_cast<const f32x4*>(kp + 4);
+    kx[0] = u.x, kx[1] = u.y, kx[2] = u.z, kx[3] = u.w, kx[4] = w.x, kx[5] = w.y, kx[6] = w.z, kx[7] = w.w;
+    const int s = v_sh >> 1, hh = v_sh & 1;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int key = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+      vx[jj] = vb[(long long)(key0 + key) * a.v_sn + v_dim];
+    }
+  };
+  auto store_tile = [&](int buf) {
+    const Pieces3 pk = split8(kx), pv = split8(vx);
+    sK[buf][0 * 8 + k_slot][k_row] = pk.h;
+    sK[buf][1 * 8 + k_slot][k_row] = pk.m;
+    sK[buf][2 * 8 + k_slot][k_row] = pk.l;
+    sV[buf][0 * 4 + v_sh][v_dim] = pv.h;
+    sV[buf][1 * 4 + v_sh][v_dim] = pv.m;
+    sV[buf][2 * 4 + v_sh][v_dim] = pv.l;
+  };
+
+  const int ntiles = blk_keys / kTK;
+  if (ntiles > 0) {
+    fetch_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    if (t * kTK < my_keys) {
+      // ---- S^T = K Q^T: 4 chunks of 16 dims x 6 piece products --------------------------------
+      f32x16 s = {0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 ak[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ak[p] = __builtin_bit_cast(bf16x8, sK[buf][p * 8 + c * 2 + h][j]);
+#define PTOPS_QK(PA, PB) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[PA], bq[PB][c], s, 0, 0, 0);
+        PTOPS_SPLIT3_TERMS(PTOPS_QK)
+#undef PTOPS_QK
+      }
+      // ---- online softmax (query = lane&31; this half holds 16 of the tile's 32 keys) ------
+      float mt = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+      mt = fmaxf(mt, other_half(mt));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += s[r];
+      }
+      l_run = l_run * alpha + psum;  // per-half partial sum; halves are added at the end
+      m_run = m_new;
+      o0 *= alpha;
+      o1 *= alpha;
+      // ---- O^T += V^T P: 2 k-steps of 16 keys x 2 dim blocks x 6 piece products -----------------
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float px[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) px[i] = s[8 * ks + i];
+        const Pieces3 pp = split8(px);
+        const bf16x8 bp[3] = {__builtin_bit_cast(bf16x8, pp.h), __builtin_bit_cast(bf16x8, pp.m), __builtin_bit_cast(bf16x8, pp.l)};
+        bf16x8 av0[3], av1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          av0[p] = __builtin_bit_cast(bf16x8, sV[buf][p * 4 + ks * 2 + h][j]);
+          av1[p] = __builtin_bit_cast(bf16x8, sV[buf][p * 4 + ks * 2 + h][32 + j]);
+        }
+#define PTOPS_PV(PA, PB)                                                          \
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0[PA], bp[PB], o0, 0, 0, 0); \
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1[PA], bp[PB], o1, 0, 0, 0);
+        PTOPS_SPLIT3_TERMS(PTOPS_PV)
+#undef PTOPS_PV
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active) {
+    const float l_tot = l_run + other_half(l_run);
+    const float inv = 1.0f / l_tot;
+    // accumulator layout: column = query (lane&31), row(reg) = (reg&3) + 8*(reg>>2) + 4*h = dim
+    float* op = a.o + (((long long)b * a.Nq + q0 + j) * a.H + head) * kD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w0 = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      f32x4 w1 = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + 8 * g + 4 * h) = w0;
+      *reinterpret_cast<f32x4*>(op + 32 + 8 * g + 4 * h) = w1;
+    }
+    if (h == 0) a.lse[((long long)b * a.H + head) * a.Nq + q0 + j] = m_run + __builtin_amdgcn_logf(l_tot);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Backward.  With P = softmax(scale q k^T), D_i = sum_c dO_ic O_ic and dS = P o (dP - D), dP = dO v^T:
 //   dq = scale dS k,   dk = scale dS^T q,   dv = P^T dO.
 // Two kernels, both deterministic (no atomics) and both built from the forward's two MFMA patterns
@@ -814,6 +1000,12 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   // where the 3-wave form (occupancy 3, 1152 workgroups on 1024 slots) needed a second, nearly empty one.
   // Measured at B=32 (benchmarks/attention_bench.py, waves 1/2/3/4): 227/180/183/146 us (576x576 masked),
   // 108/89/90/77 us (576x256), 58/47/58/43 us (256x256).
+  // >= 4 query tiles: the bf16-matrix-pipe kernel (fp32-accurate three-piece split, attn_fwd_split3_kernel);
+  // PTOPS_ATTN_FWD_F32=1 keeps the f32-MFMA kernel
+  if (tiles >= 4 && getenv("PTOPS_ATTN_FWD_F32") == nullptr) {
+    hipLaunchKernelGGL(attn_fwd_split3_kernel, dim3(ptops::ceil_div(tiles, 4), B * H), dim3(256), 0, stream, a);
+    return ptops::check_launch("attn_fwd_split3_kernel");
+  }
   int W = tiles < 4 ? tiles : 4;
   if (const char* force = getenv("PTOPS_ATTN_FWD_WAVES")) {                 // benchmarking knob
     if (force[0] >= '1' && force[0] <= '4') W = force[0] - '0';
