@@ -126,7 +126,9 @@ class ChamferProbe:
 
 class AttentionProbe:
     """Events around every attention forward / backward launch of the library (the second family of MFMA-bound
-    hand-written kernels): executed fp32 MFMA FLOP/s against the 157.3 TFLOP/s peak."""
+    hand-written kernels).  From 128 tokens up the kernels run on the bf16 matrix pipe in three-piece fp32-accurate
+    arithmetic (csrc/attention.hip: attn_fwd_split3_kernel, attn_bwd_dq_split3_kernel, attn_bwd_dkv_split3_kernel):
+    every fp32 product FLOP is executed as 6 bf16 piece-product FLOPs, priced against the 2.5 PFLOP/s dense bf16 peak."""
 
     def __init__(self):
         self.fwd, self.bwd = _native.attention_forward, _native.attention_backward
@@ -139,6 +141,13 @@ class AttentionProbe:
         Nk = k.size(2)
         return B * H * ((split_q * limit_k + (Nq - split_q) * Nk) if (split_q > 0 and limit_k < Nk) else Nq * Nk)
 
+    @staticmethod
+    def _on_bf16_pipe(q, k, backward, fused):
+        Nq, Nk = q.size(2), k.size(2)
+        if backward:
+            return (not fused) and Nq >= 128 and Nk >= 128 and "PTOPS_ATTN_BWD_F32" not in os.environ
+        return Nq >= 128 and "PTOPS_ATTN_FWD_F32" not in os.environ
+
     def forward(self, q, k, v, split_q, limit_k, scale):
         if not self.enabled:
             return self.fwd(q, k, v, split_q, limit_k, scale)
@@ -146,7 +155,8 @@ class AttentionProbe:
         s.record()
         out = self.fwd(q, k, v, split_q, limit_k, scale)
         e.record()
-        self.rec["forward"].append((s, e, 4.0 * 64 * self._pairs(q, k, split_q, limit_k)))      # 2 GEMMs
+        self.rec["forward"].append((s, e, 4.0 * 64 * self._pairs(q, k, split_q, limit_k),         # 2 GEMMs
+                                    self._on_bf16_pipe(q, k, False, False)))
         return out
 
     def backward(self, q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=True):
@@ -157,27 +167,30 @@ class AttentionProbe:
         r = self.bwd(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk, dv, fused=fused)
         e.record()
         gemms = 5.0 if fused else 7.0       # the dq + dk/dv pair evaluates S and dP twice
-        self.rec["backward"].append((s, e, 2.0 * gemms * 64 * self._pairs(q, k, split_q, limit_k)))
+        self.rec["backward"].append((s, e, 2.0 * gemms * 64 * self._pairs(q, k, split_q, limit_k),
+                                     self._on_bf16_pipe(q, k, True, fused)))
         return r
 
     def summary(self, steps):
-        out = {"bound": "mfma", "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-               "note": "fp32 v_mfma_f32_32x32x2_f32; executed MFMA FLOPs (forward 2 GEMMs, single-pass backward 5); "
-                       "pmc = separate rocprofv3 --pmc passes of the same launches (profiles/round1/attention_pmc_v2.json): "
-                       "matrix-pipe busy fraction and HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"}
-        pmc_file = os.path.join(ROOT, "profiles", "round1", "attention_pmc_v2.json")
+        out = {"bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+               "note": "achieved = fp32 product FLOPs of the launches (forward 2 GEMMs, dq + dk/dv pair 7, single-pass "
+                       "backward 5) per second; executed = x 6 for launches on the bf16 matrix pipe (three-piece split, six "
+                       "piece products per fp32 product), x 1 for the f32-MFMA kernels; frac = executed / dense bf16 peak. "
+                       "pmc = separate rocprofv3 --pmc passes of the same kernels (profiles/round2/attention_split3_pmc.json)"}
+        pmc_file = os.path.join(ROOT, "profiles", "round2", "attention_split3_pmc.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
-                out["pmc"] = [{"kernel": k["kernel"], "workgroups": k["grid_threads"] // k["workgroup"],
-                               "launch_us": k["avg_duration_us_under_pmc"], "mfma_busy": k.get("mfma_utilisation"),
-                               "traffic": k["counters"].get("hbm_traffic_bytes")} for k in json.load(fh)["kernels"]]
+                out["pmc"] = json.load(fh).get("kernels")
         for kind, recs in self.rec.items():
             if not recs:
                 continue
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+            fl = sum(f for _, _, f, _ in recs)
+            ex = sum(f * (6.0 if bf else 1.0) for _, _, f, bf in recs)
             out[kind] = {"launches_per_step": len(recs) / steps, "ms_per_step": round(ms / steps, 3),
-                         "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4)}
+                         "launches_on_bf16_pipe": sum(1 for r in recs if r[3]) / steps,
+                         "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "executed": round(ex / (ms * 1e-3) / 1e12, 1),
+                         "frac": round(ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
         return out
 
 

@@ -63,6 +63,7 @@ def main():
         from imgadapointr_amd.models import Transformer_utils as TU
         go = torch.randn(B, Nq, H, d, device="cuda")
         qr, kr, vr = (t.detach().requires_grad_(True) for t in (q, k, v))
+        default_bwd = TU.USE_MFMA_ATTENTION_BWD
         tb = {}
         for nb in ("fused", "split", False):
             TU.USE_MFMA_ATTENTION_BWD = nb
@@ -82,6 +83,7 @@ def main():
         keys_eff = (split * limit + (Nq - split) * Nk) if split else Nq * Nk
         print(f"{name:18s} backward: single-pass {tb['fused']*1e3:7.1f} us ({10.0*keys_eff*d*B*H/tb['fused']/1e9:6.1f} TF/s)  "
               f"dq + dk/dv pair {tb['split']*1e3:7.1f} us ({14.0*keys_eff*d*B*H/tb['split']/1e9:6.1f} TF/s executed)  aten {tb[False]*1e3:7.1f} us")
+        TU.USE_MFMA_ATTENTION_BWD = default_bwd
         fl = 4.0 * keys_eff * d * B * H
         print(f"{name:18s} Nq={Nq} Nk={Nk}: ours {t_ours*1e3:7.1f} us ({fl/t_ours/1e9:6.1f} TF/s)  sdpa {t_ref*1e3:7.1f} us "
               f"({4.0*Nq*Nk*d*B*H/t_ref/1e9:6.1f} TF/s)  |ours-sdpa| {err:.2e}  err64 ours {e_ours:.2e} sdpa {e_sdpa:.2e} lse {e_lse:.2e}")

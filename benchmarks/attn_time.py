@@ -1,0 +1,48 @@
+"""Event-timed forward and backward pair of one attention shape (for quick A/B runs under env switches)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imgadapointr_amd import _native as nat  # noqa: E402
+from imgadapointr_amd.models import Transformer_utils as TU  # noqa: E402
+
+SHAPES = {"self": (576, 576, 512, 512), "cross": (576, 256, 0, 256), "enc": (256, 256, 0, 256)}
+
+
+def timeit(fn, iters=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def main():
+    B, H, d = 32, 6, 64
+    torch.manual_seed(0)
+    for which in sys.argv[1:] or list(SHAPES):
+        Nq, Nk, split, limit = SHAPES[which]
+        qkv = torch.randn(B, Nq, 3, H, d, device="cuda")
+        q = qkv.permute(2, 0, 3, 1, 4)[0].detach().requires_grad_(True)
+        kv = torch.randn(B, Nk, 2, H, d, device="cuda")
+        k = kv.permute(2, 0, 3, 1, 4)[0].detach().requires_grad_(True)
+        v = kv.permute(2, 0, 3, 1, 4)[1].detach().requires_grad_(True)
+        go = torch.randn(B, Nq, H, d, device="cuda")
+        t_f = timeit(lambda: nat.attention_forward(q.detach(), k.detach(), v.detach(), split, limit, d ** -0.5))
+        res = [f"{which:6s} fwd {t_f:7.1f} us"]
+        for mode in ("split", "fused"):
+            TU.USE_MFMA_ATTENTION_BWD = mode
+            o = TU._MFMAAttention.apply(q, k, v, split, limit, d ** -0.5)
+            res.append(f"bwd[{mode}] {timeit(lambda: torch.autograd.grad(o, (q, k, v), go, retain_graph=True)):7.1f} us")
+        print("   ".join(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

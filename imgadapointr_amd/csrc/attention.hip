@@ -689,6 +689,371 @@ __global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The two-kernel backward on the bf16 matrix pipe with fp32 accuracy (round 2): the arithmetic of attn_fwd_split3_kernel
+// (three bf16 pieces per fp32 operand, six piece products per contraction on v_mfma_f32_32x32x16_bf16) applied to the
+// seven GEMMs of attn_bwd_dq_kernel / attn_bwd_dkv_kernel.  Operands meet the matrix pipe in two LDS layouts, both
+// split by the staging threads on the way in:
+//   row entries         [piece][16-dim chunk][k-half][row], rows padded to 33: A operand of "tile rows x head dims"
+//                       contractions over the head dimension (S, dP);
+//   transposed entries  [piece][k-step][k-half][dim], the 8 values of an entry being the tile rows
+//                       16 s + 8 (jj >> 2) + 4 h + (jj & 3): A operand of contractions over the tile rows (dQ^T, dK^T,
+//                       dV^T), in exactly the order in which an S / dP accumulator hands its rows over as the B operand.
+// The stationary operand (Q, dO for dq; K, V for dkv) is split once into 2 x 48 VGPRs.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs a) {
+  constexpr int W = 4;
+  constexpr int kRow = 33;
+  __shared__ uint4 sR[2][2][3 * 4 * 2][kRow];                // [buf][K | V][(piece*4 + chunk)*2 + half][key]
+  __shared__ uint4 sT[2][3 * 2 * 2][64];                     // [buf][(piece*2 + kstep)*2 + half][dim]   (K^T)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int q0 = (blockIdx.x * W + wave) * 32;
+  const bool active = q0 < a.Nq;
+  const float* kb = a.k + b * a.k_sb + head * a.k_sh;
+  const float* vb = a.v + b * a.v_sb + head * a.v_sh;
+
+  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
+  const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
+  const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
+
+  // stationary B operands: lane (j,h), chunk c holds X[q0+j][16c + 8h + 0..7] as three pieces (Q pre-scaled)
+  bf16x8 bq[3][4], bdo[3][4];
+  float lse = 0.0f, dlt = 0.0f;
+  {
+    const int qrow = active ? q0 + j : 0;
+    const float* qp = a.q + b * a.q_sb + head * a.q_sh + (long long)qrow * a.q_sn + 8 * h;
+    const long long orow = (((long long)b * a.Nq + qrow) * a.H + head) * kD + 8 * h;
+    const float* dop = a.dout + orow;
+    const float* op = a.o + orow;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x[8], y[8];
+      const f32x4 u = *reinterpret_cast<const f32x4*>(qp + 16 * c), w = *reinterpret_cast<const f32x4*>(qp + 16 * c + 4);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dop + 16 * c), d1 = *reinterpret_cast<const f32x4*>(dop + 16 * c + 4);
+      const f32x4 o0 = *reinterpret_cast<const f32x4*>(op + 16 * c), o1 = *reinterpret_cast<const f32x4*>(op + 16 * c + 4);
+      x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = w.x, x[5] = w.y, x[6] = w.z, x[7] = w.w;
+      y[0] = d0.x, y[1] = d0.y, y[2] = d0.z, y[3] = d0.w, y[4] = d1.x, y[5] = d1.y, y[6] = d1.z, y[7] = d1.w;
+      dlt = fmaf(d0.x, o0.x, dlt);
+      dlt = fmaf(d0.y, o0.y, dlt);
+      dlt = fmaf(d0.z, o0.z, dlt);
+      dlt = fmaf(d0.w, o0.w, dlt);
+      dlt = fmaf(d1.x, o1.x, dlt);
+      dlt = fmaf(d1.y, o1.y, dlt);
+      dlt = fmaf(d1.z, o1.z, dlt);
+      dlt = fmaf(d1.w, o1.w, dlt);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] = active ? x[i] * a.scale_log2e : 0.0f;
+        y[i] = active ? y[i] : 0.0f;
+      }
+      const Pieces3 p = split8(x), d = split8(y);
+      bq[0][c] = __builtin_bit_cast(bf16x8, p.h);
+      bq[1][c] = __builtin_bit_cast(bf16x8, p.m);
+      bq[2][c] = __builtin_bit_cast(bf16x8, p.l);
+      bdo[0][c] = __builtin_bit_cast(bf16x8, d.h);
+      bdo[1][c] = __builtin_bit_cast(bf16x8, d.m);
+      bdo[2][c] = __builtin_bit_cast(bf16x8, d.l);
+    }
+    dlt += other_half(dlt);
+    if (active) {
+      const long long li = ((long long)b * a.H + head) * a.Nq + q0 + j;
+      lse = a.lse[li];
+      if (h == 0) a.delta[li] = dlt;
+    }
+  }
+
+  f32x16 g0 = {0}, g1 = {0};  // dQ^T accumulators: dims 0..31 / 32..63, query on the lane
+
+  // staging: thread e owns the K and the V row entry (key e >> 3, dims 8 (e & 7) ..) and one K^T entry
+  // (dim e & 63, k-step / half e >> 6)
+  const int r_row = tid >> 3, r_oct = tid & 7;
+  const int r_slot = (r_oct >> 1) * 2 + (r_oct & 1);          // chunk * 2 + half
+  const int t_dim = tid & 63, t_sh = tid >> 6;                  // t_sh = kstep * 2 + half
+  float kx[8], vx[8], tx[8];
+  auto fetch_tile = [&](int key0) {
+    const float* kp = kb + (long long)(key0 + r_row) * a.k_sn + 8 * r_oct;
+    const float* vp = vb + (long long)(key0 + r_row) * a.v_sn + 8 * r_oct;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(kp), w = *reinterpret_cast<const f32x4*>(kp + 4);
+    const f32x4 u2 = *reinterpret_cast<const f32x4*>(vp), w2 = *reinterpret_cast<const f32x4*>(vp + 4);
+    kx[0] = u.x, kx[1] = u.y, kx[2] = u.z, kx[3] = u.w, kx[4] = w.x, kx[5] = w.y, kx[6] = w.z, kx[7] = w.w;
+    vx[0] = u2.x, vx[1] = u2.y, vx[2] = u2.z, vx[3] = u2.w, vx[4] = w2.x, vx[5] = w2.y, vx[6] = w2.z, vx[7] = w2.w;
+    const int s = t_sh >> 1, hh = t_sh & 1;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int key = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+      tx[jj] = kb[(long long)(key0 + key) * a.k_sn + t_dim];
+    }
+  };
+  auto store_tile = [&](int buf) {
+    const Pieces3 pk = split8(kx), pv = split8(vx), pt = split8(tx);
+    sR[buf][0][0 * 8 + r_slot][r_row] = pk.h;
+    sR[buf][0][1 * 8 + r_slot][r_row] = pk.m;
+    sR[buf][0][2 * 8 + r_slot][r_row] = pk.l;
+    sR[buf][1][0 * 8 + r_slot][r_row] = pv.h;
+    sR[buf][1][1 * 8 + r_slot][r_row] = pv.m;
+    sR[buf][1][2 * 8 + r_slot][r_row] = pv.l;
+    sT[buf][0 * 4 + t_sh][t_dim] = pt.h;
+    sT[buf][1 * 4 + t_sh][t_dim] = pt.m;
+    sT[buf][2 * 4 + t_sh][t_dim] = pt.l;
+  };
+
+  const int ntiles = blk_keys / kTK;
+  if (ntiles > 0) {
+    fetch_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    if (t * kTK < my_keys) {
+      // ---- S^T = K Q^T, dP^T = V dO^T: 4 chunks of 16 dims x 6 piece products each ---------------------
+      f32x16 s = {0}, dp = {0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 ak[3], av[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          ak[p] = __builtin_bit_cast(bf16x8, sR[buf][0][p * 8 + c * 2 + h][j]);
+          av[p] = __builtin_bit_cast(bf16x8, sR[buf][1][p * 8 + c * 2 + h][j]);
+        }
+#define PTOPS_SDP(PA, PB)                                                          \
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[PA], bq[PB][c], s, 0, 0, 0);  \
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA], bdo[PB][c], dp, 0, 0, 0);
+        PTOPS_SPLIT3_TERMS(PTOPS_SDP)
+#undef PTOPS_SDP
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - lse) * (dp[r] - dlt);  // dS^T (unscaled)
+      // ---- dQ^T += K^T dS^T: 2 k-steps of 16 keys x 2 dim blocks x 6 piece products ---------------------
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float px[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) px[i] = s[8 * ks + i];
+        const Pieces3 pp = split8(px);
+        const bf16x8 bp[3] = {__builtin_bit_cast(bf16x8, pp.h), __builtin_bit_cast(bf16x8, pp.m), __builtin_bit_cast(bf16x8, pp.l)};
+        bf16x8 at0[3], at1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          at0[p] = __builtin_bit_cast(bf16x8, sT[buf][p * 4 + ks * 2 + h][j]);
+          at1[p] = __builtin_bit_cast(bf16x8, sT[buf][p * 4 + ks * 2 + h][32 + j]);
+        }
+#define PTOPS_DQ(PA, PB)                                                           \
+        g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at0[PA], bp[PB], g0, 0, 0, 0);  \
+        g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at1[PA], bp[PB], g1, 0, 0, 0);
+        PTOPS_SPLIT3_TERMS(PTOPS_DQ)
+#undef PTOPS_DQ
+      }
+    }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active)
+    store_dim_major(a.dq + b * a.dq_sb + head * a.dq_sh + (long long)(q0 + j) * a.dq_sn, g0, g1, h, a.scale);
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs a) {
+  constexpr int kRow = 33;
+  __shared__ uint4 sR[2][2][3 * 4 * 2][kRow];                // [buf][Q | dO][(piece*4 + chunk)*2 + half][query]
+  __shared__ uint4 sT[2][2][3 * 2 * 2][64];                  // [buf][Q^T | dO^T][(piece*2 + kstep)*2 + half][dim]
+  __shared__ __attribute__((aligned(16))) float sL[2][2 * kTK];  // lse[32], delta[32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
+  const int k0 = (blockIdx.x * W + wave) * 32;
+  const bool active = k0 < a.Nk;
+  const float* qb = a.q + b * a.q_sb + head * a.q_sh;
+  const float* dob = a.dout + ((long long)b * a.Nq * a.H + head) * kD;  // row stride H*64
+  const float* lb = a.lse + ((long long)b * a.H + head) * a.Nq;
+  const float* db = a.delta + ((long long)b * a.H + head) * a.Nq;
+  const long long do_sn = (long long)a.H * kD;
+
+  // query tiles this workgroup walks: keys >= limit_k are seen only by queries >= split_q
+  const int blk_k0 = blockIdx.x * W * 32;
+  const int blk_qstart = (blk_k0 >= a.limit_k) ? a.split_q : 0;
+  const int my_qstart = active ? ((k0 >= a.limit_k) ? a.split_q : 0) : a.Nq;
+
+  // stationary B operands: lane (j,h), chunk c holds X[k0+j][16c + 8h + 0..7] as three pieces (K pre-scaled)
+  bf16x8 bk[3][4], bv[3][4];
+  {
+    const int krow = active ? k0 + j : 0;
+    const float* kp = a.k + b * a.k_sb + head * a.k_sh + (long long)krow * a.k_sn + 8 * h;
+    const float* vp = a.v + b * a.v_sb + head * a.v_sh + (long long)krow * a.v_sn + 8 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x[8], y[8];
+      const f32x4 u = *reinterpret_cast<const f32x4*>(kp + 16 * c), w = *reinterpret_cast<const f32x4*>(kp + 16 * c + 4);
+      const f32x4 u2 = *reinterpret_cast<const f32x4*>(vp + 16 * c), w2 = *reinterpret_cast<const f32x4*>(vp + 16 * c + 4);
+      x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = w.x, x[5] = w.y, x[6] = w.z, x[7] = w.w;
+      y[0] = u2.x, y[1] = u2.y, y[2] = u2.z, y[3] = u2.w, y[4] = w2.x, y[5] = w2.y, y[6] = w2.z, y[7] = w2.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i] = active ? x[i] * a.scale_log2e : 0.0f;
+        y[i] = active ? y[i] : 0.0f;
+      }
+      const Pieces3 p = split8(x), d = split8(y);
+      bk[0][c] = __builtin_bit_cast(bf16x8, p.h);
+      bk[1][c] = __builtin_bit_cast(bf16x8, p.m);
+      bk[2][c] = __builtin_bit_cast(bf16x8, p.l);
+      bv[0][c] = __builtin_bit_cast(bf16x8, d.h);
+      bv[1][c] = __builtin_bit_cast(bf16x8, d.m);
+      bv[2][c] = __builtin_bit_cast(bf16x8, d.l);
+    }
+  }
+
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};  // dK^T / dV^T: rows = dims, key on the lane
+
+  // staging: the tile's 1024 operand entries (256 each of Q rows, dO rows, Q^T, dO^T) over W*64 threads
+  constexpr int kPer = 1024 / (W * 64);
+  float xr[kPer][8];
+  float lreg = 0.0f;
+  auto fetch_tile = [&](int q0) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = tid + u * W * 64;
+      const int which = (e >> 8) & 1, idx = e & 255;          // e >> 9: 0 = row entries, 1 = transposed entries
+      const float* src = which ? dob : qb;
+      const long long sn = which ? do_sn : a.q_sn;
+      if (u < kPer / 2) {
+        const float* p = src + (long long)(q0 + (idx >> 3)) * sn + 8 * (idx & 7);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p), c1 = *reinterpret_cast<const f32x4*>(p + 4);
+        xr[u][0] = c0.x, xr[u][1] = c0.y, xr[u][2] = c0.z, xr[u][3] = c0.w;
+        xr[u][4] = c1.x, xr[u][5] = c1.y, xr[u][6] = c1.z, xr[u][7] = c1.w;
+      } else {
+        const int dim = idx & 63, sh = idx >> 6, s = sh >> 1, hh = sh & 1;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int row = 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+          xr[u][jj] = src[(long long)(q0 + row) * sn + dim];
+        }
+      }
+    }
+    if (tid < 64) lreg = (tid < 32) ? lb[q0 + tid] : db[q0 + tid - 32];
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int e = tid + u * W * 64;
+      const int which = (e >> 8) & 1, idx = e & 255;
+      const Pieces3 p = split8(xr[u]);
+      if (u < kPer / 2) {
+        const int row = idx >> 3, oct = idx & 7, slot = (oct >> 1) * 2 + (oct & 1);
+        sR[buf][which][0 * 8 + slot][row] = p.h;
+        sR[buf][which][1 * 8 + slot][row] = p.m;
+        sR[buf][which][2 * 8 + slot][row] = p.l;
+      } else {
+        const int dim = idx & 63, sh = idx >> 6;
+        sT[buf][which][0 * 4 + sh][dim] = p.h;
+        sT[buf][which][1 * 4 + sh][dim] = p.m;
+        sT[buf][which][2 * 4 + sh][dim] = p.l;
+      }
+    }
+    if (tid < 64) sL[buf][tid] = lreg;
+  };
+
+  const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
+  if (t_begin < t_end) {
+    fetch_tile(t_begin * kTK);
+    store_tile(t_begin & 1);
+  }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < t_end) fetch_tile((t + 1) * kTK);
+    if (t * kTK >= my_qstart) {
+      // ---- S = Q K^T, dP = dO V^T  (rows = queries (r&3)+8(r>>2)+4h, column = key j) --------------
+      f32x16 s = {0}, dp = {0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 aq[3], ao[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          aq[p] = __builtin_bit_cast(bf16x8, sR[buf][0][p * 8 + c * 2 + h][j]);
+          ao[p] = __builtin_bit_cast(bf16x8, sR[buf][1][p * 8 + c * 2 + h][j]);
+        }
+#define PTOPS_SDP(PA, PB)                                                          \
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[PA], bk[PB][c], s, 0, 0, 0);  \
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao[PA], bv[PB][c], dp, 0, 0, 0);
+        PTOPS_SPLIT3_TERMS(PTOPS_SDP)
+#undef PTOPS_SDP
+      }
+      // ---- P and dS; lse / D of the 16 query rows this half holds: 4 broadcast b128 reads each --------
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sL[buf][8 * g + 4 * h]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sL[buf][kTK + 8 * g + 4 * h]);
+        const float p0 = __builtin_amdgcn_exp2f(s[4 * g + 0] - l4.x);
+        const float p1 = __builtin_amdgcn_exp2f(s[4 * g + 1] - l4.y);
+        const float p2 = __builtin_amdgcn_exp2f(s[4 * g + 2] - l4.z);
+        const float p3 = __builtin_amdgcn_exp2f(s[4 * g + 3] - l4.w);
+        s[4 * g + 0] = p0;
+        s[4 * g + 1] = p1;
+        s[4 * g + 2] = p2;
+        s[4 * g + 3] = p3;
+        dp[4 * g + 0] = p0 * (dp[4 * g + 0] - d4.x);
+        dp[4 * g + 1] = p1 * (dp[4 * g + 1] - d4.y);
+        dp[4 * g + 2] = p2 * (dp[4 * g + 2] - d4.z);
+        dp[4 * g + 3] = p3 * (dp[4 * g + 3] - d4.w);
+      }
+      // ---- dV^T += dO^T P, dK^T += Q^T dS: 2 k-steps of 16 queries x 2 dim blocks x 6 piece products each ----
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float px[8], dx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          px[i] = s[8 * ks + i];
+          dx[i] = dp[8 * ks + i];
+        }
+        {
+          const Pieces3 pp = split8(px);
+          const bf16x8 bp[3] = {__builtin_bit_cast(bf16x8, pp.h), __builtin_bit_cast(bf16x8, pp.m), __builtin_bit_cast(bf16x8, pp.l)};
+          bf16x8 at0[3], at1[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            at0[p] = __builtin_bit_cast(bf16x8, sT[buf][1][p * 4 + ks * 2 + h][j]);
+            at1[p] = __builtin_bit_cast(bf16x8, sT[buf][1][p * 4 + ks * 2 + h][32 + j]);
+          }
+#define PTOPS_DV(PA, PB)                                                             \
+          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at0[PA], bp[PB], dv0, 0, 0, 0); \
+          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at1[PA], bp[PB], dv1, 0, 0, 0);
+          PTOPS_SPLIT3_TERMS(PTOPS_DV)
+#undef PTOPS_DV
+        }
+        {
+          const Pieces3 pd = split8(dx);
+          const bf16x8 bd[3] = {__builtin_bit_cast(bf16x8, pd.h), __builtin_bit_cast(bf16x8, pd.m), __builtin_bit_cast(bf16x8, pd.l)};
+          bf16x8 at0[3], at1[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            at0[p] = __builtin_bit_cast(bf16x8, sT[buf][0][p * 4 + ks * 2 + h][j]);
+            at1[p] = __builtin_bit_cast(bf16x8, sT[buf][0][p * 4 + ks * 2 + h][32 + j]);
+          }
+#define PTOPS_DK(PA, PB)                                                             \
+          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at0[PA], bd[PB], dk0, 0, 0, 0); \
+          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at1[PA], bd[PB], dk1, 0, 0, 0);
+          PTOPS_SPLIT3_TERMS(PTOPS_DK)
+#undef PTOPS_DK
+        }
+      }
+    }
+    if (t + 1 < t_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (active) {
+    store_dim_major(a.dk + b * a.dk_sb + head * a.dk_sh + (long long)(k0 + j) * a.dk_sn, dk0, dk1, h, a.scale);
+    store_dim_major(a.dv + b * a.dv_sb + head * a.dv_sh + (long long)(k0 + j) * a.dv_sn, dv0, dv1, h, 1.0f);
+  }
+}
+
+
 // ---- single-pass backward: dk, dv and dq from ONE evaluation of S and dP (5 GEMMs) ----------------------------
 // Eight waves per workgroup, each with a stationary 32-key tile (K^T, V^T in registers, dK^T / dV^T accumulators),
 // walk the query tiles together.  dQ[32 q x 64 dims] = dS[q x 256 keys] K[keys x dims] needs dS with the QUERY as the
@@ -1053,6 +1418,22 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
   a.dv_sb = dv_strides[0]; a.dv_sh = dv_strides[1]; a.dv_sn = dv_strides[2];
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  // >= 4 tiles on both sides: the bf16-matrix-pipe pair (fp32-accurate three-piece split); PTOPS_ATTN_BWD_F32=1 keeps
+  // the f32-MFMA kernels for A/B runs
+  static const bool f32_only = getenv("PTOPS_ATTN_BWD_F32") != nullptr;
+  if (!f32_only && Nq >= 128 && Nk >= 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_split3_kernel, dim3(ptops::ceil_div(Nq / 32, 4), B * H), dim3(256), 0, stream, a);
+    int rc = ptops::check_launch("attn_bwd_dq_split3_kernel");
+    if (rc != PTOPS_OK) return rc;
+    const int ktiles = Nk / 32;
+    const char* dkv_env = getenv("PTOPS_ATTN_DKV_WAVES");
+    const int dkv_waves = dkv_env ? atoi(dkv_env) : 8;
+    if (dkv_waves == 4)
+      hipLaunchKernelGGL(attn_bwd_dkv_split3_kernel<4>, dim3(ptops::ceil_div(ktiles, 4), B * H), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(attn_bwd_dkv_split3_kernel<8>, dim3(ptops::ceil_div(ktiles, 8), B * H), dim3(512), 0, stream, a);
+    return ptops::check_launch("attn_bwd_dkv_split3_kernel");
+  }
   {  // dq (+ delta): one wave per 32-query tile; two waves per SIMD fit, so 4-wave workgroups (two per CU)
      // fill a CU where 3-wave ones would leave a quarter of it empty; the last workgroup may be partly idle
     const int tiles = Nq / 32;

@@ -30,9 +30,11 @@ USE_SDPA = True
 # Head-dim-64 attention on libptops' fp32 MFMA kernels (csrc/attention.hip); the backward variant is chosen below.
 # Falls back to SDPA for shapes the kernels do not cover (token counts that are not multiples of 32).
 USE_MFMA_ATTENTION = True
-# "fused": single-pass MFMA backward (5 GEMMs); "split": the dq + dk/dv kernel pair (7 GEMMs);
+# "split": the dq + dk/dv kernel pair (7 GEMMs; on the bf16 matrix pipe in three-piece fp32-accurate arithmetic from
+# 128 tokens up: 352 / 176 / 117 us at the bs = 32 decoder-self / cross / encoder shapes);
+# "fused": the single-pass f32-MFMA backward (5 GEMMs; 430 / 206 / 114 us);
 # False: PyTorch-ROCm's aten::_efficient_attention_backward, which consumes the same (out, logsumexp) pair
-USE_MFMA_ATTENTION_BWD = "fused"
+USE_MFMA_ATTENTION_BWD = "split"
 _LN2 = 0.6931471805599453
 _bias_cache = {}
 _zero_cache = {}

@@ -392,6 +392,7 @@ def test_packed_self_attention_and_linear_bias_grad(native):
     mask = torch.zeros(576, 576, device="cuda")
     mask[:512, 512:] = 1.
     outs = {}
+    default_bwd = TU.USE_MFMA_ATTENTION_BWD
     for fast, native_bwd in ((True, "fused"), (True, "split"), (True, False), (False, False)):
         TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = fast
         TU.USE_MFMA_ATTENTION_BWD = native_bwd
@@ -401,7 +402,7 @@ def test_packed_self_attention_and_linear_bias_grad(native):
         g = torch.autograd.grad(y.square().sum(), [x] + list(attn.parameters()))
         outs[(fast, native_bwd)] = [y.detach()] + [t.detach() for t in g]
     TU.USE_MFMA_ATTENTION = TU.FAST_BIAS_GRAD = True
-    TU.USE_MFMA_ATTENTION_BWD = "fused"
+    TU.USE_MFMA_ATTENTION_BWD = default_bwd
     for key in ((True, "fused"), (True, "split"), (True, False)):
         for a, b in zip(outs[key], outs[(False, False)]):
             scale = max(1.0, b.abs().max().item())
