@@ -35,7 +35,7 @@ def main():
               (18432, 1024, 1024), (18432, 384, 1024), (8192, 384, 384), (8192, 1152, 384), (8192, 768, 384),
               (8192, 384, 768), (16384, 512, 512), (65536, 512, 512), (18432, 512, 768)]
     print(f"{'M':>6} {'N':>5} {'K':>5} | fwd x.W^T: torch us  split3 us  speedup | dgrad dy.W: torch  split3  speedup | "
-          f"wgrad dy^T.x: torch  split3 | rel err vs f64: torch  split3")
+          f"wgrad dy^T.x: torch  split3 (+db) | rel err vs f64: torch  split3")
     tot_t = tot_s = 0.0
     for M, N, K in shapes:
         x = torch.randn(M, K, device=dev)
@@ -61,18 +61,19 @@ def main():
         s_d = timed(lambda: _native.gemm_split3(dy, w, None, True, False))
         # weight gradient: dw = dy^T x  (A logical [N, M]: stored dy [M, N] = k strided; B logical [K_in, M]: stored x [M, K_in])
         dw_t = dy.t() @ x
-        dw_s = _native.gemm_split3(dy, x, None, False, False)
+        dw_s, db_s = _native.gemm_split3_wgrad(dy, x, True)
         refw = dy.double().t() @ x.double()
         ew_t = float((dw_t.double() - refw).abs().max()) / float(refw.abs().max())
         ew_s = float((dw_s.double() - refw).abs().max()) / float(refw.abs().max())
         t_w = timed(lambda: dy.t() @ x)
-        s_w = timed(lambda: _native.gemm_split3(dy, x, None, False, False))
+        s_w = timed(lambda: _native.gemm_split3_wgrad(dy, x, True))
+        e_b = float((db_s.double() - dy.double().sum(0)).abs().max()) / float(dy.double().sum(0).abs().max())
         tot_t += t_f + t_d
         tot_s += s_f + s_d
         tf = 2.0 * M * N * K / 1e6
         print(f"{M:6d} {N:5d} {K:5d} | {t_f:8.1f} ({tf / t_f:5.0f} TF) {s_f:8.1f} ({tf / s_f:5.0f} TF) {t_f / s_f:5.2f}x | "
               f"{t_d:8.1f} {s_d:8.1f} {t_d / s_d:5.2f}x | {t_w:8.1f} {s_w:8.1f} | "
-              f"fwd {e_t:.1e} {e_s:.1e}  dgrad {ed_t:.1e} {ed_s:.1e}  wgrad {ew_t:.1e} {ew_s:.1e}", flush=True)
+              f"fwd {e_t:.1e} {e_s:.1e}  dgrad {ed_t:.1e} {ed_s:.1e}  wgrad {ew_t:.1e} {ew_s:.1e}  db {e_b:.1e}", flush=True)
     print(f"sum fwd + dgrad: torch {tot_t:.0f} us, split3 {tot_s:.0f} us")
 
 

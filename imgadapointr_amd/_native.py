@@ -61,6 +61,9 @@ def _declare(lib):
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
         "ptops_gemm_f32_split3": (c_int, [P, ctypes.c_longlong, c_int, P, ctypes.c_longlong, c_int, P, ctypes.c_longlong,
                                           c_int, c_int, c_int, P, P]),
+        "ptops_gemm_f32_split3_wgrad_workspace": (ctypes.c_longlong, [c_int, c_int, c_int]),
+        "ptops_gemm_f32_split3_wgrad": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, c_int, c_int, c_int, P,
+                                                ctypes.c_longlong, P, P, ctypes.c_longlong, P]),
         "ptops_max_tokens_backward": (c_int, [P, P, c_int, c_int, c_int, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
         "ptops_layer_norm_max_dim": (c_int, []),
@@ -94,6 +97,7 @@ EXPORTS = (
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
+    "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
@@ -650,6 +654,27 @@ def gemm_split3(a, b, bias=None, a_k_contiguous=True, b_k_contiguous=True, out=N
         _call("ptops_gemm_f32_split3", _ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous),
               _ptr(out), out.stride(0), M, N, K, _ptr(bias) if bias is not None else None, _stream(a))
     return out
+
+
+def gemm_split3_wgrad(dy, x, want_bias=False):
+    """Weight (and bias) gradient of a dense layer on the bf16 matrix pipe: dy [M,N], x [M,K] (fp32, unit inner stride)
+    -> (dy^T . x [N,K], column sums of dy [N] or None).  M % 16 == 0, K % 4 == 0 (and N % 4 == 0 with want_bias)."""
+    for name, t in (("dy", dy), ("x", x)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise ValueError(f"gemm_split3_wgrad: {name} must be a 2-D fp32 CUDA tensor with unit inner stride")
+    _same_device(dy, x)
+    M, N = dy.shape
+    if x.shape[0] != M:
+        raise ValueError(f"gemm_split3_wgrad: row counts differ ({M} vs {x.shape[0]})")
+    K = x.shape[1]
+    with torch.cuda.device(dy.device):
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+        db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+        need = int(load().ptops_gemm_f32_split3_wgrad_workspace(M, N, K))
+        ws = torch.empty((max(need, 16),), dtype=torch.uint8, device=dy.device)
+        _call("ptops_gemm_f32_split3_wgrad", _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dw), dw.stride(0),
+              _ptr(db) if db is not None else None, _ptr(ws), need, _stream(dy))
+    return dw, db
 
 
 def _scratch(dev, stream, need):

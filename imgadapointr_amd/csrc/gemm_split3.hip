@@ -176,6 +176,132 @@ __global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
   }
 }
 
+
+// ---- weight gradient: dW[N,K] = dY[M,N]^T . X[M,K] (+ db[N] = column sums of dY), contraction over the M rows -------
+// Same tile, staging and arithmetic as gemm_split3_kernel<false, false> (both operands "k strided": an operand entry is
+// 8 consecutive rows m of one column, read as 8 dwords that are coalesced across the lanes), but the output is small
+// (N x K of a layer: 9 .. 108 tiles) and the contraction long (M = 8192 .. 65536), so the k-steps are split over
+// gridDim.y workgroups per tile: each writes its 128 x 128 partial to the workspace and wgrad_reduce_kernel adds the
+// partials in a fixed order (deterministic, no atomics).  The column sums of dY (the layer's bias gradient) fall out of
+// the A staging: every A entry passes through one thread's registers exactly once.
+struct WgradArgs {
+  const float* dY;   // [M, ldy]
+  const float* X;    // [M, ldx]
+  float* part;       // [splits][N][K] partial products
+  float* bpart;      // [splits][N] partial column sums, or null
+  long long ldy, ldx;
+  int M, N, K;       // M: contraction; output N x K
+  int tiles_k;       // tiles along K (the output's columns)
+  int steps_per_split;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) {
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+  __shared__ float sB[256];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  const int bid = blockIdx.x, split = blockIdx.y;
+  const int tile_n = bid / g.tiles_k, tile_k = bid - tile_n * g.tiles_k;
+  const int n0 = tile_n * kBM, c0 = tile_k * kBN;              // output rows (N) / columns (K)
+  const bool stage_b = t >= 256;
+  const int tt = t & 255;
+  const int e = entry_index<false>(tt);
+  const int ks_total = g.M / kBK;
+  const int ks_begin = split * g.steps_per_split, ks_end = min(ks_begin + g.steps_per_split, ks_total);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float x[8];
+  float bsum = 0.f;                                            // A stagers: sum of this thread's dY entries
+  auto load = [&](int ks) {
+    if (stage_b) load_entry<false>(g.X, g.ldx, g.K, c0, ks * kBK, tt, x);
+    else load_entry<false>(g.dY, g.ldy, g.N, n0, ks * kBK, tt, x);
+  };
+  auto store = [&](int buf) {
+    bsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    const Pieces p = split8(x);
+    uint4(*dst)[2 * kPlane] = lds[buf][stage_b ? 1 : 0];
+    dst[0][e] = p.h, dst[1][e] = p.m, dst[2][e] = p.l;
+  };
+  if (ks_begin < ks_end) {
+    load(ks_begin);
+    store(0);
+  }
+  __syncthreads();
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int cur = (ks - ks_begin) & 1;
+    const bool more = ks + 1 < ks_end;
+    if (more) load(ks + 1);
+    bf16x8 a[3], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a[p] = __builtin_bit_cast(bf16x8, lds[cur][0][p][half * kPlane + wr * 32 + col]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[p][j] = __builtin_bit_cast(bf16x8, lds[cur][1][p][half * kPlane + wc * 64 + j * 32 + col]);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      const int pa = term == 0 ? 2 : ((term == 1 || term == 3) ? 1 : 0);
+      const int pb = term == 2 ? 2 : ((term == 1 || term == 4) ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb][j], acc[j], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* part = g.part + (long long)split * g.N * g.K;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + wc * 64 + j * 32 + col;
+    if (c >= g.K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < g.N) part[(long long)n * g.K + c] = acc[j][r];
+    }
+  }
+  if (g.bpart && tile_k == 0) {                                // every tile_k sees the same dY rows: one of them reports
+    if (!stage_b) sB[tt] = bsum;                               // entry tt: row tt & 127, k-half tt >> 7
+    __syncthreads();
+    if (t < 128 && n0 + t < g.N) g.bpart[(long long)split * g.N + n0 + t] = sB[t] + sB[t + 128];
+  }
+}
+
+// out[i] = sum over the splits, in order; 4 elements per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long count, int splits,
+                                                           float* __restrict__ out, long long ld_out, int cols) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;
+  float4 s = *reinterpret_cast<const float4*>(part + i);
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long long)k * count + i);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  const long long row = i / cols;
+  const int c = (int)(i - row * cols);
+  *reinterpret_cast<float4*>(out + row * ld_out + c) = s;
+}
+
+// splits of the contraction: about two workgroups per CU in total, at least 8 k-steps each
+static int wgrad_splits(int M, int N, int K) {
+  const int tiles = ptops::ceil_div(N, kBM) * ptops::ceil_div(K, kBN);
+  const int ksteps = M / kBK;
+  int s = ptops::ceil_div(512, tiles);
+  s = s < 1 ? 1 : s;
+  const int max_s = ksteps / 8 > 0 ? ksteps / 8 : 1;
+  s = s > max_s ? max_s : s;
+  s = s > 64 ? 64 : s;
+  const int per = ptops::ceil_div(ksteps, s);
+  return ptops::ceil_div(ksteps, per);                         // no empty split
+}
+
 }  // namespace
 
 // C[M,N] = opA . opB^T + bias.  a_k_contiguous: A is stored [M, lda] (k contiguous) else [K, lda] (m contiguous);
@@ -203,4 +329,45 @@ PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_conti
   else if (b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, block, 0, stream, g);
   return ptops::check_launch("gemm_split3_kernel");
+}
+
+PTOPS_API long long ptops_gemm_f32_split3_wgrad_workspace(int M, int N, int K) {
+  if (M < 16 || N < 1 || K < 1) return 0;
+  const long long s = wgrad_splits(M, N, K);
+  return s * ((long long)N * K + N) * (long long)sizeof(float);
+}
+
+// dW[N,K] = dY[M,N]^T . X[M,K];  db[N] = column sums of dY when db != null.  M % 16 == 0, K % 4 == 0, lddw % 4 == 0.
+PTOPS_API int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, long long ldx, int M, int N,
+                                          int K, float* dW, long long lddw, float* db, void* workspace,
+                                          long long workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_split3_wgrad: negative size");
+  if (N == 0 || K == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(dY && X && dW && workspace, "gemm_f32_split3_wgrad: null pointer");
+  PTOPS_REQUIRE(M >= 16 && M % 16 == 0, "gemm_f32_split3_wgrad: M must be a positive multiple of 16 (M=%d)", M);
+  PTOPS_REQUIRE(K % 4 == 0 && lddw % 4 == 0 && ((uintptr_t)dW & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                "gemm_f32_split3_wgrad: output rows must be 16-byte aligned");
+  PTOPS_REQUIRE(workspace_bytes >= ptops_gemm_f32_split3_wgrad_workspace(M, N, K), "gemm_f32_split3_wgrad: workspace too small");
+  if (db) PTOPS_REQUIRE(N % 4 == 0 && ((uintptr_t)db & 15) == 0, "gemm_f32_split3_wgrad: db must be 16-byte aligned, N %% 4 == 0");
+  const int splits = wgrad_splits(M, N, K);
+  WgradArgs g;
+  g.dY = dY, g.X = X, g.ldy = ldy, g.ldx = ldx;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_k = ptops::ceil_div(K, kBN);
+  g.steps_per_split = ptops::ceil_div(M / kBK, splits);
+  g.part = (float*)workspace;
+  g.bpart = db ? g.part + (long long)splits * N * K : nullptr;
+  dim3 grid((unsigned)(ptops::ceil_div(N, kBM) * g.tiles_k), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_split3_wgrad_kernel, grid, dim3(512), 0, stream, g);
+  int rc = ptops::check_launch("gemm_split3_wgrad_kernel");
+  if (rc != PTOPS_OK) return rc;
+  const long long count = (long long)N * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptops::ceil_div_ll(count, 1024)), dim3(256), 0, stream, g.part, count,
+                     splits, dW, lddw, K);
+  rc = ptops::check_launch("wgrad_reduce_kernel");
+  if (rc != PTOPS_OK || !db) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptops::ceil_div_ll(N, 1024)), dim3(256), 0, stream, g.bpart,
+                     (long long)N, splits, db, (long long)N, N);
+  return ptops::check_launch("wgrad_reduce_kernel");
 }

@@ -88,6 +88,20 @@ def _use_split3_dgrad(g2, weight):
             and K >= 128 and M >= 16384 and (N >= 512 or K >= 1024))
 
 
+USE_SPLIT3_WGRAD = os.environ.get("PTOPS_SPLIT3_WGRAD", "1") != "0"
+
+
+def _use_split3_wgrad(g2, x2):
+    """dy^T.x on the split-bf16 kernel with the contraction split over workgroups: ahead of the library's split-K fp32
+    kernels (and it delivers the bias gradient in the same pass) for long contractions and outputs of >= 48 tiles'
+    worth of work (benchmarks/gemm_split3_probe.py: 18432 x 1152 x 384 154 vs 155 + 15 us, 18432 x 1024 x 1024 262 vs
+    314, 65536 x 512 x 512 251 vs 306; 18432 x 384 x 384 72 vs 56 + 8 and everything at 8192 rows stay on the library)."""
+    M, N = g2.shape
+    K = x2.size(1)
+    return (USE_SPLIT3_WGRAD and _split3_ok(g2, 16) and _split3_ok(x2, 16) and M >= 16384 and M % 16 == 0 and K % 4 == 0
+            and N * K >= 393216 and min(N, K) >= 128)
+
+
 def linear_forward(x, weight, bias):
     """F.linear(x, weight, bias), on the split-bf16 GEMM where that is the faster fp32-accurate kernel."""
     K = x.size(-1)
@@ -100,8 +114,8 @@ def linear_forward(x, weight, bias):
 
 class _LinearFn(torch.autograd.Function):
     """F.linear whose bias gradient is libptops' streaming column sum (csrc/reduce.hip) instead of the
-    generic 2-5 workgroup reduction autograd would run; forward and input-gradient GEMMs go to the split-bf16 kernel
-    where it wins, the weight gradient stays on the library's split-K kernels."""
+    generic 2-5 workgroup reduction autograd would run; forward, input-gradient and weight-gradient GEMMs go to the
+    split-bf16 kernels where they win (the weight-gradient kernel also returns the bias gradient)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -118,12 +132,18 @@ class _LinearFn(torch.autograd.Function):
                 gx = _native.gemm_split3(g2, weight, None, True, False).view(x.shape)
             else:
                 gx = (g2 @ weight).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            gw = g2.t() @ x.reshape(-1, x.size(-1))
         if ctx.needs_input_grad[2]:
             gb = _take_column_sums(grad)
-            if gb is None:
-                gb = _native.colsum(g2.contiguous())
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.size(-1))
+            if _use_split3_wgrad(g2, x2):
+                # the bias gradient (column sums of g2) falls out of the same pass
+                gw, db = _native.gemm_split3_wgrad(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
+                gb = db if db is not None else gb
+            else:
+                gw = g2.t() @ x2
+        if ctx.needs_input_grad[2] and gb is None:
+            gb = _native.colsum(g2.contiguous())
         return gx, gw, gb
 
 

@@ -314,6 +314,16 @@ int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, con
                           int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
                           void* stream);
 
+/* Weight gradient of the same layers: dW[N,K] = dY[M,N]^T . X[M,K] and, when db != NULL, db[N] = the column sums of dY
+ * (the bias gradient; the rows of dY pass through the staging registers anyway).  The long contraction (M rows) is
+ * split over several workgroups per 128 x 128 output tile, whose partial products go to `workspace` and are added in
+ * a fixed order by a second kernel: deterministic, no atomics, no memset.  M % 16 == 0; K % 4 == 0 and N % 4 == 0
+ * (with db); dW rows, db and the workspace 16-byte aligned; *_workspace gives the bytes needed for a shape. */
+long long ptops_gemm_f32_split3_wgrad_workspace(int M, int N, int K);
+int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, long long ldx, int M, int N, int K,
+                                float* dW, long long lddw, float* db, void* workspace, long long workspace_bytes,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -487,9 +487,39 @@ def test_gemm_split3_is_fp32_accurate(native, M, N, K):
         native.gemm_split3(torch.randn(M, 20, device="cuda")[:, 1:17], w[:, :16])      # rows start 4 bytes off a 16-byte boundary
 
 
+@pytest.mark.parametrize("M,N,K", [(18432, 384, 384), (8192, 1152, 384), (2048, 200, 132), (16, 128, 128), (4096, 4, 4),
+                                   (65536, 512, 1024)])
+def test_gemm_split3_wgrad_and_bias_gradient(native, M, N, K):
+    """dW = dy^T.x with the contraction split over workgroups, and db = column sums of dy from the same pass: fp32
+    accuracy against float64 (not worse than the library GEMM / torch.sum), ragged tiles, row-sliced views,
+    bit-identical repeats (fixed reduction order)."""
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda") * torch.logspace(-2, 2, K, device="cuda")
+    dy = torch.randn(M, N, device="cuda") + 0.25
+
+    def rel(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    dw, db = native.gemm_split3_wgrad(dy, x, True)
+    assert rel(dw, ref_w) <= max(4.0 * rel(dy.t() @ x, ref_w), 1e-5), (rel(dw, ref_w), rel(dy.t() @ x, ref_w))
+    assert rel(db, ref_b) <= max(4.0 * rel(dy.sum(0), ref_b), 1e-5), (rel(db, ref_b), rel(dy.sum(0), ref_b))
+    dw2, db2 = native.gemm_split3_wgrad(dy, x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw3, none = native.gemm_split3_wgrad(dy, x, False)
+    assert none is None and torch.equal(dw, dw3)
+    xv = torch.randn(M, K + 8, device="cuda")[:, 4:4 + K]
+    dyv = torch.randn(M, N + 4, device="cuda")[:, :N]
+    dwv, dbv = native.gemm_split3_wgrad(dyv, xv, True)
+    assert rel(dwv, dyv.double().t() @ xv.double()) < 2e-5 and rel(dbv, dyv.double().sum(0)) < 2e-5
+    if M > 16:
+        with pytest.raises(native.PtopsError):
+            native.gemm_split3_wgrad(dy[:M - 8], x[:M - 8])             # M % 16 != 0
+
+
 def test_linear_layers_on_split3_match_library(native):
     """nn.Linear-compatible module: forward, input gradient, weight gradient and bias gradient with the split-bf16 GEMM
-    switched on and off agree to fp32 accuracy (the weight gradient is the library's either way)."""
+    switched on and off agree to fp32 accuracy (each is compared with float64)."""
     from imgadapointr_amd.models import Transformer_utils as TU
     torch.manual_seed(21)
     lin = TU.Linear(384, 1152).cuda()
@@ -509,7 +539,10 @@ def test_linear_layers_on_split3_match_library(native):
     for a, bq, ref in ((res[True][0], res[False][0], ref_y), (res[True][1], res[False][1], ref_gx)):
         ea, eb = float((a.double() - ref).abs().max()), float((bq.double() - ref).abs().max())
         assert ea <= max(2.0 * eb, 1e-6 * float(ref.abs().max())), (ea, eb)
-    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+    g2, x2 = g.view(-1, 1152).double(), x.detach().view(-1, 384).double()
+    for a, bq, ref in ((res[True][2], res[False][2], g2.t() @ x2), (res[True][3], res[False][3], g2.sum(0))):
+        ea, eb = float((a.double() - ref).abs().max()), float((bq.double() - ref).abs().max())
+        assert ea <= max(2.0 * eb, 1e-6 * float(ref.abs().max())), (ea, eb)
 
 
 def test_bias_gradient_handoff_ignores_other_layouts(native):
