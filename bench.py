@@ -180,7 +180,9 @@ class AttentionProbe:
         pmc_file = os.path.join(ROOT, "profiles", "round2", "attention_split3_pmc.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
-                out["pmc"] = json.load(fh).get("kernels")
+                out["pmc"] = [{"kernel": k["kernel"], "workgroups": k["grid_threads"] // k["workgroup"],
+                               "launch_us": k["avg_duration_us_under_pmc"], "mfma_busy": k.get("mfma_utilisation"),
+                               "traffic": k["counters"].get("hbm_traffic_bytes")} for k in json.load(fh)["kernels"]]
         for kind, recs in self.rec.items():
             if not recs:
                 continue

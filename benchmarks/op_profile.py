@@ -45,6 +45,14 @@ def main():
     print(f"\nnon-GEMM aten ops: {tot / 3e3:.3f} ms per step")
     for e in rows[:90]:
         print(f"{e.self_device_time_total / 3e3:8.3f} ms  x{e.count / 3:6.1f}  {e.key:38s} {str(e.input_shapes)[:150]}")
+    # the library GEMMs by shape (which dense layers still run on hipBLASLt / rocBLAS)
+    rows = [e for e in prof.key_averages(group_by_input_shape=True)
+            if e.key in ("aten::mm", "aten::addmm", "aten::bmm") and getattr(e, "self_device_time_total", 0) > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    tot = sum(e.self_device_time_total for e in rows)
+    print(f"\nlibrary GEMMs (aten::mm / addmm / bmm): {tot / 3e3:.3f} ms per step")
+    for e in rows[:60]:
+        print(f"{e.self_device_time_total / 3e3:8.3f} ms  x{e.count / 3:6.1f}  {e.key:12s} {str(e.input_shapes)[:120]}")
 
 
 if __name__ == "__main__":

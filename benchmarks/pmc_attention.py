@@ -49,7 +49,14 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
             simd_cycles = avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
             rec["mfma_utilisation"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4)
-            rec["equivalent_fp32_mfma_tflops"] = round(rec["mfma_utilisation"] * 157.3, 1)
+            if "split3" in key[0]:       # bf16 matrix pipe: 2.5 PFLOP/s dense when busy every cycle at the peak clock
+                rec["executed_bf16_tflops_at_peak_clock"] = round(rec["mfma_utilisation"] * 2500.0, 1)
+            else:
+                rec["equivalent_fp32_mfma_tflops"] = round(rec["mfma_utilisation"] * 157.3, 1)
+            if "SQ_ACTIVE_INST_VALU" in avg:
+                rec["valu_busy"] = round(avg["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles, 4)
+            if d:
+                rec["clock_ghz"] = round(avg["GRBM_GUI_ACTIVE"] / 8.0 / (sum(d) / len(d)), 3)
         out.append(rec)
     print(json.dumps({"note": __doc__.strip().splitlines()[-2] + " " + __doc__.strip().splitlines()[-1], "kernels": out}, indent=1))
 

@@ -19,11 +19,12 @@ FAMILIES = [
     ("ptops: fps", r"fps_kernel"),
     ("ptops: edge-conv", r"edge_[a-z_]+kernel"),
     ("ptops: gather/index", r"gather_|index_points"),
-    ("ptops: attention fwd", r"attn_fwd_kernel"),
+    ("ptops: attention fwd", r"attn_fwd_"),
     ("ptops: attention bwd", r"attn_bwd_|attn_dq_reduce|attn_dkv_reduce"),
     ("ptops: layernorm", r"ln_fwd_kernel|ln_bwd_kernel"),
     ("ptops: colsum", r"colsum_"),
     ("ptops: batchnorm rows", r"bn_[a-z_]+kernel"),
+    ("ptops: GEMM (fp32 on the bf16 pipe)", r"gemm_split3|wgrad_reduce"),
     ("attention bwd (aten)", r"fmha|attention|AttentionBackward|efficient_attention"),
     ("GEMM (hipBLASLt/rocBLAS/CK)", r"^Cijk_|gemm|Gemm"),
     ("conv (MIOpen)", r"conv|Conv|igemm|miopen"),
