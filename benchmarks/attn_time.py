@@ -27,13 +27,17 @@ def timeit(fn, iters=30):
 def main():
     B, H, d = 32, 6, 64
     torch.manual_seed(0)
+    contiguous = os.environ.get("ATTN_LAYOUT", "packed") == "contiguous"    # packed: views of [B,N,3,H,d] as in the model
     for which in sys.argv[1:] or list(SHAPES):
         Nq, Nk, split, limit = SHAPES[which]
         qkv = torch.randn(B, Nq, 3, H, d, device="cuda")
-        q = qkv.permute(2, 0, 3, 1, 4)[0].detach().requires_grad_(True)
+        q = qkv.permute(2, 0, 3, 1, 4)[0].detach()
         kv = torch.randn(B, Nk, 2, H, d, device="cuda")
-        k = kv.permute(2, 0, 3, 1, 4)[0].detach().requires_grad_(True)
-        v = kv.permute(2, 0, 3, 1, 4)[1].detach().requires_grad_(True)
+        k = kv.permute(2, 0, 3, 1, 4)[0].detach()
+        v = kv.permute(2, 0, 3, 1, 4)[1].detach()
+        if contiguous:
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        q, k, v = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
         go = torch.randn(B, Nq, H, d, device="cuda")
         t_f = timeit(lambda: nat.attention_forward(q.detach(), k.detach(), v.detach(), split, limit, d ** -0.5))
         res = [f"{which:6s} fwd {t_f:7.1f} us"]
