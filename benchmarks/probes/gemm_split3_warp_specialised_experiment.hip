@@ -1,0 +1,539 @@
+// fp32 GEMM on the bf16 matrix pipe: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]), fp32 in, fp32 out, gfx950 (MI355X).
+//
+// The dense layers of the path (models/Transformer_utils.py:71-159 of the reference: nn.Linear forward and backward)
+// are fp32 GEMMs; gfx950 has no TF32-like mode and its f32 MFMA runs at the f32 vector rate (157 TFLOP/s), where the
+// library kernels already sit at 70-90 %.  The bf16 MFMA is 16x faster, so each f32 operand is split in the kernel into
+// three bf16 pieces, x = h + m + l (round to nearest; exact to 2^-27 |x|), and every k-step issues the six piece
+// products down to 2^-18: Ah.Bh, Ah.Bm, Am.Bh, Ah.Bl, Am.Bm, Al.Bh.  bf16 x bf16 products are exact in f32 and the
+// MFMA accumulates in f32 (measured in chamfer_mfma.hip: like a single-rounding f32 sum), the dropped products are
+// <= 3 * 2^-26 |a||b| per term: the result is as close to the exact product as an f32 FMA chain is (tests compare both
+// with float64).  6 MFMA per k-step at 16x the rate = 2.7x the f32 matrix peak at equal clocks.
+//
+// Tiling: 128 x 128 output tile per workgroup (8 waves, 32 x 64 each = 1 x 2 MFMA blocks of 32 x 32), k-step 16.
+// Staging: every thread loads the 8 f32 of ONE operand entry (row, k-half), splits them and writes the three 16-byte
+// bf16 entries to LDS ([piece][k-half][row], conflict-free ds_read_b128); the next k-step's loads are in flight while
+// the current one computes; double-buffered LDS, one barrier per k-step.  Either operand may be stored with k
+// contiguous ([rows, ld]) or with k strided ([K, ld], rows contiguous): the strided form reads 8 coalesced dwords
+// instead of two dwordx4, so A.B^T (forward), A.B (input gradient) and A^T.B (weight gradient) use one kernel.
+#include "ptops_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBM = 128, kBN = 128, kBK = 16;
+// entries per k-half plane: 128 rows + 4 of padding, so that the 8 lanes of a ds_write_b128 group (rows r .. r+3 of both
+// k-halves when k is contiguous) fall on 8 different 16-byte bank groups; reads stay consecutive within a half
+constexpr int kPlane = 132;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;   // [N] or null
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int tiles_n;
+};
+
+struct Pieces {
+  uint4 h, m, l;
+};
+
+// 8 f32 -> three 8 x bf16 entries
+__device__ __forceinline__ Pieces split8(const float (&x)[8]) {
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    h[i] = a;
+    m[i] = b;
+    l[i] = c;
+  }
+  Pieces p;
+  p.h = __builtin_bit_cast(uint4, h);
+  p.m = __builtin_bit_cast(uint4, m);
+  p.l = __builtin_bit_cast(uint4, l);
+  return p;
+}
+
+// One operand entry of the tile that starts at row r0 / k-step k0: 8 consecutive k of one row.
+//   KC (k contiguous, [rows, ld]): thread t -> row t >> 1, k-half t & 1
+//   else (k strided,  [K, ld])   : thread t -> row t & 127, k-half t >> 7
+template <bool KC>
+__device__ __forceinline__ void load_entry(const float* __restrict__ P, long long ld, int rows, int r0, int k0, int t,
+                                           float (&x)[8]) {
+  if (KC) {
+    const int row = min(r0 + (t >> 1), rows - 1);
+    const float4* p = reinterpret_cast<const float4*>(P + (long long)row * ld + k0 + 8 * (t & 1));
+    const float4 u = p[0], v = p[1];
+    x[0] = u.x, x[1] = u.y, x[2] = u.z, x[3] = u.w, x[4] = v.x, x[5] = v.y, x[6] = v.z, x[7] = v.w;
+  } else {
+    const int row = min(r0 + (t & 127), rows - 1);
+    const float* p = P + (long long)(k0 + 8 * (t >> 7)) * ld + row;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = p[(long long)i * ld];
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ int entry_index(int t) {
+  return KC ? ((t & 1) * kPlane + (t >> 1)) : ((t >> 7) * kPlane + (t & 127));
+}
+
+// 8 waves per 128 x 128 tile: wave w owns rows (w >> 1) * 32 .. + 31 and columns (w & 1) * 64 .. + 63 (two MFMA blocks).
+// Thread t < 256 stages A entry t, thread t >= 256 stages B entry t - 256 (one entry = 8 f32 of one row -> 3 x 16 bytes).
+// With 4 waves per tile and 432 tiles (M = 18432, N = 384) a SIMD mostly hosts ONE wave, whose LDS / staging / barrier
+// phases leave the matrix pipe idle; 8 waves put two waves of every tile on each SIMD (107 -> ? TFLOP/s).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
+  // [buffer][operand][piece][k-half * kPlane + row]
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give every XCD one contiguous range of tiles, so that
+  // the tiles_n tiles that read the same 128 rows of A do so through one L2 (bijective for any grid; speed only).
+  int bid;
+  {
+    const int orig = blockIdx.x, nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
+  const int m0 = tile_m * kBM, n0 = tile_n * kBN;
+  const bool stage_b = t >= 256;
+  const int tt = t & 255;
+  const int e = stage_b ? entry_index<BKC>(tt) : entry_index<AKC>(tt);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float x[8];
+  auto load = [&](int k0) {
+    if (stage_b) load_entry<BKC>(g.B, g.ldb, g.N, n0, k0, tt, x);
+    else load_entry<AKC>(g.A, g.lda, g.M, m0, k0, tt, x);
+  };
+  auto store = [&](int buf) {
+    const Pieces p = split8(x);
+    uint4(*dst)[2 * kPlane] = lds[buf][stage_b ? 1 : 0];
+    dst[0][e] = p.h, dst[1][e] = p.m, dst[2][e] = p.l;
+  };
+  load(0);
+  store(0);
+  __syncthreads();
+
+  // (Tried: waves w and w + 4 — SIMD partners — staggered, one splitting / storing the next k-step before its MFMAs
+  // and one after, with loads two k-steps ahead: 112 VGPRs instead of 79 and 3-30 % slower.)
+  // Tried on this loop, none faster (profiles/round2/gemm_split3_notes.txt): global loads two k-steps ahead with a raw
+  // s_barrier so that they stay in flight (0-8 % slower: 9 more VGPRs, 8 v_mov per step); SIMD partners (waves w, w + 4)
+  // staggered, one splitting / storing before its MFMAs and one after (3-30 % slower); 4 waves of 64 x 64 (10 % slower:
+  // one wave per SIMD on most CUs at 432 tiles).
+  const int ksteps = g.K / kBK;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < ksteps;
+    if (more) load((ks + 1) * kBK);          // next k-step: global -> registers now, split + LDS after the math
+    bf16x8 a[3], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a[p] = __builtin_bit_cast(bf16x8, lds[cur][0][p][half * kPlane + wr * 32 + col]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[p][j] = __builtin_bit_cast(bf16x8, lds[cur][1][p][half * kPlane + wc * 64 + j * 32 + col]);
+    }
+    // six piece products per block, smallest first; the two blocks alternate so that no MFMA waits on the one before
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      // (piece of A, piece of B): (l,h) (m,m) (h,l) (m,h) (h,m) (h,h)
+      const int pa = term == 0 ? 2 : ((term == 1 || term == 3) ? 1 : 0);
+      const int pb = term == 2 ? 2 : ((term == 1 || term == 4) ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb][j], acc[j], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: block j register r holds C[m0 + wr*32 + (r&3) + 8 (r>>2) + 4 half][n0 + wc*64 + j*32 + col]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 64 + j * 32 + col;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < g.M) g.C[(long long)m * g.ldc + n] = acc[j][r] + bv;
+    }
+  }
+}
+
+
+// ---- warp-specialised forward kernel (A and B k-contiguous) --------------------------------------------------------
+// The loop of gemm_split3_kernel is serialised inside the workgroup by its barrier: fragment-read burst, the MFMAs of the
+// two waves of a SIMD one after the other, split + ds_write burst, barrier (stamps: profiles/round2/gemm_split3_notes.txt).
+// Here the two waves of a SIMD have different jobs and no workgroup barrier separates them:
+//   waves 4-7 (producers, one per SIMD): global loads one k-step ahead, split, ds_write into a ring of kRing LDS slots;
+//   waves 0-3 (consumers, one per SIMD): ds_read + 24 MFMAs per k-step on a 64 x 64 quadrant of the 128 x 128 tile,
+//                                        fragments of step s + 1 read before the MFMAs of step s are issued.
+// Hand-off by two monotonic LDS counters per slot: ready[slot] (+1 per producer wave once its ds_writes of a step have
+// completed) and done[slot] (+1 per consumer wave once its reads of a step have completed); a wave polls with a relaxed
+// LDS load + s_sleep.  The vector work of a k-step (100 instructions per producer wave) runs on the vector ALU while the
+// consumer wave of the same SIMD keeps the matrix pipe busy.  Every poll loop is bounded, so a logic error shows up as a
+// wrong result flagged in g_ws_timeout, not as a hung GPU.
+constexpr int kRing = 4;   // the producer loop below is unrolled by the ring length
+__device__ int g_ws_timeout;
+
+__device__ __forceinline__ bool ws_wait(unsigned* flag, unsigned target) {
+  for (int spin = 0; spin < (1 << 14); ++spin) {
+    const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(v) >= target) {
+      asm volatile("" ::: "memory");       // data reads stay behind the poll
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+__device__ __forceinline__ void ws_signal(unsigned* flag, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes / reads of the step have completed
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(512) void gemm_split3_ws_kernel(GemmArgs g) {
+  // [ring slot][operand][piece][k-half * kPlane + row]
+  __shared__ uint4 lds[kRing][2][3][2 * kPlane];
+  __shared__ unsigned ready[kRing], done[kRing];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  int bid;
+  {
+    const int orig = blockIdx.x, nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
+  const int m0 = tile_m * kBM, n0 = tile_n * kBN;
+  const int ksteps = g.K / kBK;
+  if (t < kRing) ready[t] = 0, done[t] = 0;
+  __syncthreads();                                    // the only workgroup barrier
+
+  if (wave >= 4) {
+    // ---------------- producer: entry pt of A and entry pt of B per k-step ----------------
+    const int pt = t - 256;
+    const int e = entry_index<true>(pt);
+    // four register sets: a set is split and stored at its step and immediately re-loaded with the data of the step four
+    // ahead, so every global load has ~3 k-steps (> 2000 cycles) to arrive
+    float xa[4][8], xb[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = min(u, ksteps - 1) * kBK;
+      load_entry<true>(g.A, g.lda, g.M, m0, k0, pt, xa[u]);
+      load_entry<true>(g.B, g.ldb, g.N, n0, k0, pt, xb[u]);
+    }
+    bool ok = true;
+    for (int s0 = 0; s0 < ksteps; s0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u;
+        const int slot = u;                           // kRing == 4: step s lives in slot s & 3
+        const Pieces pa = split8(xa[u]), pb = split8(xb[u]);
+        const int k4 = min(s + 4, ksteps - 1) * kBK;  // clamped past the end: loaded, never used
+        load_entry<true>(g.A, g.lda, g.M, m0, k4, pt, xa[u]);
+        load_entry<true>(g.B, g.ldb, g.N, n0, k4, pt, xb[u]);
+        if (s < ksteps) {
+          if (s >= kRing) ok &= ws_wait(&done[slot], 4u * (unsigned)(s / kRing));   // the slot's previous step has been read
+          lds[slot][0][0][e] = pa.h, lds[slot][0][1][e] = pa.m, lds[slot][0][2][e] = pa.l;
+          lds[slot][1][0][e] = pb.h, lds[slot][1][1][e] = pb.m, lds[slot][1][2][e] = pb.l;
+          ws_signal(&ready[slot], lane);
+        }
+      }
+    }
+    if (!ok && lane == 0) atomicAdd(&g_ws_timeout, 1);
+    return;
+  }
+
+  // ---------------- consumer: 64 x 64 quadrant (cm, cn), 2 x 2 MFMA blocks ----------------
+  const int cm = wave >> 1, cn = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  struct Frag {
+    bf16x8 a[2][3], b[2][3];
+  };
+  auto read = [&](int slot, Frag& f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        f.a[i][p] = __builtin_bit_cast(bf16x8, lds[slot][0][p][half * kPlane + cm * 64 + i * 32 + col]);
+        f.b[i][p] = __builtin_bit_cast(bf16x8, lds[slot][1][p][half * kPlane + cn * 64 + i * 32 + col]);
+      }
+  };
+  auto math = [&](const Frag& f) {
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      const int pa = term == 0 ? 2 : ((term == 1 || term == 3) ? 1 : 0);
+      const int pb = term == 2 ? 2 : ((term == 1 || term == 4) ? 1 : 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[j][pb], acc[i][j], 0, 0, 0);
+    }
+  };
+  bool ok = ws_wait(&ready[0], 4u);
+  Frag f0, f1;
+  read(0, f0);
+  auto step = [&](const Frag& cur, Frag& nxt, int s) {
+    const int slot = s & (kRing - 1);
+    if (s + 1 < ksteps) {
+      const int s1 = (s + 1) & (kRing - 1);
+      ok &= ws_wait(&ready[s1], 4u * (unsigned)((s + 1) / kRing + 1));
+      read(s1, nxt);                                  // in flight under the MFMAs below
+    }
+    math(cur);
+    ws_signal(&done[slot], lane);                     // (its lgkmcnt(0) also covers the reads of nxt)
+  };
+  for (int s = 0; s < ksteps; s += 2) {
+    step(f0, f1, s);
+    if (s + 1 < ksteps) step(f1, f0, s + 1);
+  }
+  if (!ok && lane == 0) atomicAdd(&g_ws_timeout, 1);
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + cn * 64 + j * 32 + col;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + cm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) g.C[(long long)m * g.ldc + n] = acc[i][j][r] + bv;
+      }
+  }
+}
+
+// ---- weight gradient: dW[N,K] = dY[M,N]^T . X[M,K] (+ db[N] = column sums of dY), contraction over the M rows -------
+// Same tile, staging and arithmetic as gemm_split3_kernel<false, false> (both operands "k strided": an operand entry is
+// 8 consecutive rows m of one column, read as 8 dwords that are coalesced across the lanes), but the output is small
+// (N x K of a layer: 9 .. 108 tiles) and the contraction long (M = 8192 .. 65536), so the k-steps are split over
+// gridDim.y workgroups per tile: each writes its 128 x 128 partial to the workspace and wgrad_reduce_kernel adds the
+// partials in a fixed order (deterministic, no atomics).  The column sums of dY (the layer's bias gradient) fall out of
+// the A staging: every A entry passes through one thread's registers exactly once.
+struct WgradArgs {
+  const float* dY;   // [M, ldy]
+  const float* X;    // [M, ldx]
+  float* part;       // [splits][N][K] partial products
+  float* bpart;      // [splits][N] partial column sums, or null
+  long long ldy, ldx;
+  int M, N, K;       // M: contraction; output N x K
+  int tiles_k;       // tiles along K (the output's columns)
+  int steps_per_split;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) {
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+  __shared__ float sB[256];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int col = lane & 31, half = lane >> 5;
+  const int bid = blockIdx.x, split = blockIdx.y;
+  const int tile_n = bid / g.tiles_k, tile_k = bid - tile_n * g.tiles_k;
+  const int n0 = tile_n * kBM, c0 = tile_k * kBN;              // output rows (N) / columns (K)
+  const bool stage_b = t >= 256;
+  const int tt = t & 255;
+  const int e = entry_index<false>(tt);
+  const int ks_total = g.M / kBK;
+  const int ks_begin = split * g.steps_per_split, ks_end = min(ks_begin + g.steps_per_split, ks_total);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float x[8];
+  float bsum = 0.f;                                            // A stagers: sum of this thread's dY entries
+  auto load = [&](int ks) {
+    if (stage_b) load_entry<false>(g.X, g.ldx, g.K, c0, ks * kBK, tt, x);
+    else load_entry<false>(g.dY, g.ldy, g.N, n0, ks * kBK, tt, x);
+  };
+  auto store = [&](int buf) {
+    bsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    const Pieces p = split8(x);
+    uint4(*dst)[2 * kPlane] = lds[buf][stage_b ? 1 : 0];
+    dst[0][e] = p.h, dst[1][e] = p.m, dst[2][e] = p.l;
+  };
+  if (ks_begin < ks_end) {
+    load(ks_begin);
+    store(0);
+  }
+  __syncthreads();
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int cur = (ks - ks_begin) & 1;
+    const bool more = ks + 1 < ks_end;
+    if (more) load(ks + 1);
+    bf16x8 a[3], b[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a[p] = __builtin_bit_cast(bf16x8, lds[cur][0][p][half * kPlane + wr * 32 + col]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[p][j] = __builtin_bit_cast(bf16x8, lds[cur][1][p][half * kPlane + wc * 64 + j * 32 + col]);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      const int pa = term == 0 ? 2 : ((term == 1 || term == 3) ? 1 : 0);
+      const int pb = term == 2 ? 2 : ((term == 1 || term == 4) ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb][j], acc[j], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* part = g.part + (long long)split * g.N * g.K;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + wc * 64 + j * 32 + col;
+    if (c >= g.K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < g.N) part[(long long)n * g.K + c] = acc[j][r];
+    }
+  }
+  if (g.bpart && tile_k == 0) {                                // every tile_k sees the same dY rows: one of them reports
+    if (!stage_b) sB[tt] = bsum;                               // entry tt: row tt & 127, k-half tt >> 7
+    __syncthreads();
+    if (t < 128 && n0 + t < g.N) g.bpart[(long long)split * g.N + n0 + t] = sB[t] + sB[t + 128];
+  }
+}
+
+// out[i] = sum over the splits, in order; 4 elements per thread
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long count, int splits,
+                                                           float* __restrict__ out, long long ld_out, int cols) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;
+  float4 s = *reinterpret_cast<const float4*>(part + i);
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long long)k * count + i);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  const long long row = i / cols;
+  const int c = (int)(i - row * cols);
+  *reinterpret_cast<float4*>(out + row * ld_out + c) = s;
+}
+
+// splits of the contraction: about two workgroups per CU in total, at least 8 k-steps each
+static int wgrad_splits(int M, int N, int K) {
+  const int tiles = ptops::ceil_div(N, kBM) * ptops::ceil_div(K, kBN);
+  const int ksteps = M / kBK;
+  int s = ptops::ceil_div(512, tiles);
+  s = s < 1 ? 1 : s;
+  const int max_s = ksteps / 8 > 0 ? ksteps / 8 : 1;
+  s = s > max_s ? max_s : s;
+  s = s > 64 ? 64 : s;
+  const int per = ptops::ceil_div(ksteps, s);
+  return ptops::ceil_div(ksteps, per);                         // no empty split
+}
+
+}  // namespace
+
+PTOPS_API int ptops_debug_gemm_ws_timeouts(void) {
+  int v = -1;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ws_timeout), sizeof(int)) != hipSuccess) return -1;
+  return v;
+}
+
+// C[M,N] = opA . opB^T + bias.  a_k_contiguous: A is stored [M, lda] (k contiguous) else [K, lda] (m contiguous);
+// b_k_contiguous: B is stored [N, ldb] else [K, ldb].  K % 16 == 0; a k-contiguous operand needs 16-byte aligned rows.
+PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
+                                    int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_split3: negative size");
+  if (M == 0 || N == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(A && B && C, "gemm_f32_split3: null pointer");
+  PTOPS_REQUIRE(K >= 16 && K % 16 == 0, "gemm_f32_split3: K must be a positive multiple of 16 (K=%d)", K);
+  if (a_k_contiguous) PTOPS_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0, "gemm_f32_split3: A rows must be 16-byte aligned");
+  if (b_k_contiguous) PTOPS_REQUIRE(ldb % 4 == 0 && ((uintptr_t)B & 15) == 0, "gemm_f32_split3: B rows must be 16-byte aligned");
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = bias;
+  g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_n = ptops::ceil_div(N, kBN);
+  const long long blocks = (long long)ptops::ceil_div(M, kBM) * g.tiles_n;
+  PTOPS_REQUIRE(blocks < (1LL << 31), "gemm_f32_split3: grid too large");
+  dim3 grid((unsigned)blocks), block(512);
+  static const bool use_ws = getenv("PTOPS_GEMM_WS") != nullptr;
+  if (use_ws && a_k_contiguous && b_k_contiguous) {
+    hipLaunchKernelGGL(gemm_split3_ws_kernel, grid, block, 0, stream, g);
+    return ptops::check_launch("gemm_split3_ws_kernel");
+  }
+  if (a_k_contiguous && b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, block, 0, stream, g);
+  else if (a_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, block, 0, stream, g);
+  else if (b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, block, 0, stream, g);
+  return ptops::check_launch("gemm_split3_kernel");
+}
+
+PTOPS_API long long ptops_gemm_f32_split3_wgrad_workspace(int M, int N, int K) {
+  if (M < 16 || N < 1 || K < 1) return 0;
+  const long long s = wgrad_splits(M, N, K);
+  return s * ((long long)N * K + N) * (long long)sizeof(float);
+}
+
+// dW[N,K] = dY[M,N]^T . X[M,K];  db[N] = column sums of dY when db != null.  M % 16 == 0, K % 4 == 0, lddw % 4 == 0.
+PTOPS_API int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, long long ldx, int M, int N,
+                                          int K, float* dW, long long lddw, float* db, void* workspace,
+                                          long long workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_split3_wgrad: negative size");
+  if (N == 0 || K == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(dY && X && dW && workspace, "gemm_f32_split3_wgrad: null pointer");
+  PTOPS_REQUIRE(M >= 16 && M % 16 == 0, "gemm_f32_split3_wgrad: M must be a positive multiple of 16 (M=%d)", M);
+  PTOPS_REQUIRE(K % 4 == 0 && lddw % 4 == 0 && ((uintptr_t)dW & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                "gemm_f32_split3_wgrad: output rows must be 16-byte aligned");
+  PTOPS_REQUIRE(workspace_bytes >= ptops_gemm_f32_split3_wgrad_workspace(M, N, K), "gemm_f32_split3_wgrad: workspace too small");
+  if (db) PTOPS_REQUIRE(N % 4 == 0 && ((uintptr_t)db & 15) == 0, "gemm_f32_split3_wgrad: db must be 16-byte aligned, N %% 4 == 0");
+  const int splits = wgrad_splits(M, N, K);
+  WgradArgs g;
+  g.dY = dY, g.X = X, g.ldy = ldy, g.ldx = ldx;
+  g.M = M, g.N = N, g.K = K;
+  g.tiles_k = ptops::ceil_div(K, kBN);
+  g.steps_per_split = ptops::ceil_div(M / kBK, splits);
+  g.part = (float*)workspace;
+  g.bpart = db ? g.part + (long long)splits * N * K : nullptr;
+  dim3 grid((unsigned)(ptops::ceil_div(N, kBM) * g.tiles_k), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_split3_wgrad_kernel, grid, dim3(512), 0, stream, g);
+  int rc = ptops::check_launch("gemm_split3_wgrad_kernel");
+  if (rc != PTOPS_OK) return rc;
+  const long long count = (long long)N * K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptops::ceil_div_ll(count, 1024)), dim3(256), 0, stream, g.part, count,
+                     splits, dW, lddw, K);
+  rc = ptops::check_launch("wgrad_reduce_kernel");
+  if (rc != PTOPS_OK || !db) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptops::ceil_div_ll(N, 1024)), dim3(256), 0, stream, g.bpart,
+                     (long long)N, splits, db, (long long)N, N);
+  return ptops::check_launch("wgrad_reduce_kernel");
+}
