@@ -3,7 +3,8 @@
 Replaces the reference's `nn.parallel.DistributedDataParallel(..., find_unused_parameters=True)`
 (tools/runner.py:83-93).  Design for MI355X's point-to-point xGMI fabric:
   * gradients are averaged in a few large contiguous fp32 buckets, so a collective moves one large
-    message per bucket instead of many 25 MB ones;
+    message per bucket instead of many 25 MB ones; the buckets shrink towards the end of backward (64, 33, 16, 8, 8 MB
+    for AdaPoinTr), because the last one to complete is the only collective that cannot hide behind backward;
   * buckets are laid out in reverse parameter order (the order backward produces gradients).  During
     backward every parameter's `.grad` is the tensor autograd produced (no accumulate-into-zero kernels:
     `.grad` is None when backward starts); when the LAST gradient of a bucket arrives, its hook packs
@@ -64,13 +65,23 @@ class FlatDDP(nn.Module):
 
     # ------------------------------------------------------------------ bucket construction
     def _build_buckets(self, used_params):
+        # Backward order; bucket sizes shrink towards the end of backward: the bucket that completes last (the first
+        # layers' gradients) is the one collective nothing can overlap, so it should be small, while the early ones
+        # have the rest of backward to hide behind and can be large: cap = min(bucket_bytes, half of what is left),
+        # at least min(8 MB, bucket_bytes).  AdaPoinTr (130 MB): 64, 33, 16, 8, 8 MB.
+        sizes = [p.numel() * p.element_size() for p in reversed(used_params)]
+        remaining = sum(sizes)
+        floor_bytes = min(8 << 20, self.bucket_bytes)
+        cap = max(floor_bytes, min(self.bucket_bytes, remaining // 2))
         buckets, cur, cur_bytes = [], [], 0
-        for p in reversed(used_params):
+        for p, nbytes in zip(reversed(used_params), sizes):
             cur.append(p)
-            cur_bytes += p.numel() * p.element_size()
-            if cur_bytes >= self.bucket_bytes:
+            cur_bytes += nbytes
+            if cur_bytes >= cap:
                 buckets.append(cur)
+                remaining -= cur_bytes
                 cur, cur_bytes = [], 0
+                cap = max(floor_bytes, min(self.bucket_bytes, remaining // 2))
         if cur:
             buckets.append(cur)
         self._buckets = []
