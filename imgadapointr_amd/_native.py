@@ -58,6 +58,8 @@ def _declare(lib):
         "ptops_edge_norm_backward": (c_int, [P] * 10 + [c_int] * 6 + [ctypes.c_float] + [P] * 5),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
+        "ptops_fold_defer": (c_int, [c_int]),
+        "ptops_fold_flush": (c_int, [P]),
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
         "ptops_gemm_f32_split3": (c_int, [P, ctypes.c_longlong, c_int, P, ctypes.c_longlong, c_int, P, ctypes.c_longlong,
                                           c_int, c_int, c_int, P, P]),
@@ -96,6 +98,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
+    "ptops_fold_defer", "ptops_fold_flush",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
     "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
@@ -586,6 +589,69 @@ def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk,
 _colsum_ws = {}
 
 
+# ---- deferred folds (include/ptops.h): the tiny final launches of the column-sum producers, batched -----------------
+_fold_deferred = False
+_fold_keepalive = []          # workspaces / outputs of queued folds: alive until the flush
+_fold_seen = set()            # parameters that already got a (possibly still queued) gradient in this backward pass
+
+
+class deferred_folds:
+    """Context manager for a backward pass whose bias / LayerNorm-weight gradients are read only afterwards (or after a
+    `fold_flush()`, as FlatDDP does before it packs a bucket): the ~115 fold launches become a few batched ones.
+    Do NOT use it when `.grad` already holds a value that backward accumulates into (gradient accumulation)."""
+
+    def __enter__(self):
+        global _fold_deferred
+        _fold_seen.clear()
+        if _test_backend is None:
+            load().ptops_fold_defer(1)
+            _fold_deferred = True
+        return self
+
+    def __exit__(self, *exc):
+        global _fold_deferred
+        if _fold_deferred:
+            _fold_deferred = False
+            load().ptops_fold_defer(0)
+            fold_flush()
+        return False
+
+
+def fold_returning(key):
+    """Call where a backward node hands a possibly queued gradient of parameter `key` (any hashable, e.g. its
+    data_ptr) to autograd.  The first gradient of a parameter is adopted unread; a SECOND one in the same backward
+    pass (a module applied twice) is added to the first by the engine at once, so everything queued is folded first."""
+    if _fold_deferred:
+        if key in _fold_seen:
+            fold_flush()
+        else:
+            _fold_seen.add(key)
+
+
+def fold_flush():
+    """Runs the queued folds on the current stream (no-op when nothing is queued)."""
+    if _fold_keepalive:
+        dev = _fold_keepalive[0].device
+        with torch.cuda.device(dev):
+            _call("ptops_fold_flush", ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _fold_keepalive.clear()
+
+
+def _fold_workspace(dev, stream, need, *outs):
+    """The workspace of a column-sum producer: the shared per-stream scratch, or - under `deferred_folds` - a buffer of
+    its own that stays alive (with the outputs) until the flush."""
+    if not _fold_deferred:
+        return _scratch(dev, stream, need)
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    _fold_keepalive.append(ws)
+    for out in outs:
+        # the storage must outlive the queued fold even if autograd drops the gradient, but the tensor object itself
+        # must not gain a reference (AccumulateGrad only adopts a gradient it holds the sole reference to - otherwise
+        # it would clone, i.e. READ, the not yet written values): keep a base-less alias of the storage
+        _fold_keepalive.append(torch.empty(0, dtype=out.dtype, device=dev).set_(out.untyped_storage()))
+    return ws
+
+
 def colsum(x):
     """x [M,N] float32 contiguous (N % 4 == 0) -> column sums [N] (deterministic)."""
     if _test_backend is not None:
@@ -595,12 +661,8 @@ def colsum(x):
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device)
         need = max(load().ptops_colsum_workspace_bytes(M, N), 16)
-        key = (x.device.index, stream.cuda_stream)
-        ws = _colsum_ws.get(key)
-        if ws is None or ws.numel() < need:          # one scratch buffer per (device, stream), grown on demand
-            ws = torch.empty((max(need, 1 << 22),), dtype=torch.uint8, device=x.device)
-            _colsum_ws[key] = ws
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
+        ws = _fold_workspace(x.device, stream, need, out)
         _call("ptops_colsum", _ptr(x), M, N, _ptr(out), _ptr(ws), ctypes.c_void_p(stream.cuda_stream))
     return out
 
@@ -747,9 +809,9 @@ def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
             raise ValueError("layer_norm_backward: extra must match x")
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        ws = _scratch(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16))
         dx = torch.empty_like(x)
         dgb = torch.empty((3 * C,), dtype=torch.float32, device=dev)
+        ws = _fold_workspace(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16), dgb)
         _call("ptops_layer_norm_backward", _ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(weight),
               _ptr(extra) if extra is not None else None, rows, C, _ptr(dx), _ptr(dgb), _ptr(ws),
               ctypes.c_void_p(stream.cuda_stream))
@@ -766,9 +828,9 @@ def gelu_backward_colsum(x, dy):
         raise ValueError("gelu_backward_colsum: shapes differ")
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        ws = _scratch(dev, stream, max(load().ptops_gelu_backward_colsum_workspace_bytes(M, N), 16))
         dpre = torch.empty_like(x)
         cs = torch.empty((N,), dtype=torch.float32, device=dev)
+        ws = _fold_workspace(dev, stream, max(load().ptops_gelu_backward_colsum_workspace_bytes(M, N), 16), cs)
         _call("ptops_gelu_backward_colsum", _ptr(x), _ptr(dy), M, N, _ptr(dpre), _ptr(cs), _ptr(ws),
               ctypes.c_void_p(stream.cuda_stream))
     return dpre, cs

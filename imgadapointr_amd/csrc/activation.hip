@@ -74,5 +74,5 @@ PTOPS_API int ptops_gelu_backward_colsum(const float* x, const float* dy, int M,
                      (float*)workspace);
   int rc = ptops::check_launch("gelu_bwd_colsum_kernel");
   if (rc != PTOPS_OK) return rc;
-  return ptops_reduce::fold_rows((const float*)workspace, S, N, colsum, stream);
+  return ptops_reduce::fold_rows((const float*)workspace, S, N, colsum, stream, true);
 }

@@ -296,5 +296,5 @@ PTOPS_API int ptops_layer_norm_backward(const float* dy, const float* x, const f
   int rc = ptops::check_launch("ln_bwd_kernel");
   if (rc != PTOPS_OK) return rc;
   // dgamma | dbeta | colsum(dx)  [3C] = column sums of the [blocks <= 1024, 3C] partial rows: one fold launch
-  return ptops_reduce::fold_rows(partial, (int)blocks, 3 * C, dgamma_dbeta, stream);
+  return ptops_reduce::fold_rows(partial, (int)blocks, 3 * C, dgamma_dbeta, stream, true);
 }

@@ -33,9 +33,12 @@ constexpr int kWave = 64;
 
 }  // namespace ptops
 
-// reduce.hip: out[n] = sum over the S rows of partial [S, N] in a fixed order, one launch (N % 4 == 0)
+// reduce.hip: out[n] = sum over the S rows of partial [S, N] in a fixed order, one launch (N % 4 == 0).
+// `deferrable`: the result is a leaf gradient nobody reads before the end of backward - while ptops_fold_defer(1) is
+// in force the fold is queued instead of launched and ptops_fold_flush() runs all queued folds in one or two launches
+// (same summation order as the immediate launch).
 namespace ptops_reduce {
-int fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream);
+int fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream, bool deferrable = false);
 }
 
 // chamfer_sweep.hip: exact pruned Chamfer search (sort by x + bounded sweep)

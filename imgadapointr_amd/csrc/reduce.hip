@@ -7,6 +7,9 @@
 // writing one partial row.  A second small launch adds the S partials in a fixed order (deterministic, no
 // atomics, no device-wide fences: a single-launch variant with a "last workgroup folds" ticket was 5x
 // slower because every workgroup's release fence writes back its XCD's L2).
+#include <mutex>
+#include <vector>
+
 #include "ptops_common.h"
 
 namespace {
@@ -103,12 +106,125 @@ __global__ __launch_bounds__(16 * RY) void colsum_final_kernel(const float* __re
 
 }  // namespace
 
-int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream) {
+// ---- deferred folds: the ~115 tiny fold launches of a backward pass (bias, LayerNorm and GELU-bias gradients) as a few
+// batched ones.  One GPU per process; the queue is process-wide because autograd runs backward nodes on its own thread.
+namespace {
+
+constexpr int kMaxBatch = 96;
+struct FoldBatch {
+  const float* partial[kMaxBatch];
+  float* out[kMaxBatch];
+  int S[kMaxBatch];
+  int N[kMaxBatch];
+  int first_block[kMaxBatch + 1];   // prefix sums of ceil(N / 64)
+  int count;
+};
+
+// the body of colsum_final_kernel<RY> for item `it`, column block `cb`
+template <int RY>
+__global__ __launch_bounds__(16 * RY) void colsum_final_batched_kernel(FoldBatch b) {
+  __shared__ float4 red[RY / 4][16];
+  int it = 0;
+  while (it + 1 < b.count && (int)blockIdx.x >= b.first_block[it + 1]) ++it;   // uniform, <= 96 steps
+  const float* __restrict__ partial = b.partial[it];
+  const int S = b.S[it], N = b.N[it];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = (((int)blockIdx.x - b.first_block[it]) * 16 + cx) * 4;
+  const bool in = col < N;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    for (int t = ry; t < S; t += RY) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)t * N + col);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+  }
+  if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && in) {
+    float4 s = red[0][cx];
+#pragma unroll
+    for (int t = 1; t < RY / 4; ++t) {
+      const float4 v = red[t][cx];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(b.out[it] + col) = s;
+  }
+}
+
+struct PendingFold {
+  const float* partial;
+  float* out;
+  int S, N;
+};
+std::mutex g_fold_mutex;
+std::vector<PendingFold> g_pending;
+bool g_defer = false;
+
+template <int RY>
+int launch_batches(const std::vector<PendingFold>& items, hipStream_t stream) {
+  size_t i = 0;
+  while (i < items.size()) {
+    FoldBatch b;
+    b.count = 0;
+    b.first_block[0] = 0;
+    while (i < items.size() && b.count < kMaxBatch) {
+      const PendingFold& f = items[i++];
+      b.partial[b.count] = f.partial, b.out[b.count] = f.out, b.S[b.count] = f.S, b.N[b.count] = f.N;
+      b.first_block[b.count + 1] = b.first_block[b.count] + ptops::ceil_div(f.N, 64);
+      ++b.count;
+    }
+    hipLaunchKernelGGL(colsum_final_batched_kernel<RY>, dim3(b.first_block[b.count]), dim3(16 * RY), 0, stream, b);
+    const int rc = ptops::check_launch("colsum_final_batched_kernel");
+    if (rc != PTOPS_OK) return rc;
+  }
+  return PTOPS_OK;
+}
+
+}  // namespace
+
+int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream, bool deferrable) {
+  if (deferrable) {
+    std::lock_guard<std::mutex> lock(g_fold_mutex);
+    if (g_defer) {
+      g_pending.push_back({partial, out, S, N});
+      return PTOPS_OK;
+    }
+  }
   if (S > 64)
     hipLaunchKernelGGL(colsum_final_kernel<64>, dim3(ptops::ceil_div(N, 64)), dim3(1024), 0, stream, partial, S, N, out);
   else
     hipLaunchKernelGGL(colsum_final_kernel<16>, dim3(ptops::ceil_div(N, 64)), dim3(256), 0, stream, partial, S, N, out);
   return ptops::check_launch("colsum_final_kernel");
+}
+
+// on != 0: deferrable folds (ptops_colsum, ptops_layer_norm_backward, ptops_gelu_backward_colsum) are queued until
+// ptops_fold_flush; the caller keeps their workspaces and outputs alive and unread until then.  Returns the number of
+// folds still queued (switching off does not flush).
+PTOPS_API int ptops_fold_defer(int on) {
+  std::lock_guard<std::mutex> lock(g_fold_mutex);
+  g_defer = on != 0;
+  return (int)g_pending.size();
+}
+
+// Launches every queued fold on `stream` (the stream their producers ran on): one launch per 96 folds and size class.
+PTOPS_API int ptops_fold_flush(void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<PendingFold> small, large;
+  {
+    std::lock_guard<std::mutex> lock(g_fold_mutex);
+    for (const PendingFold& f : g_pending) (f.S > 64 ? large : small).push_back(f);
+    g_pending.clear();
+  }
+  int rc = launch_batches<16>(small, stream);
+  if (rc != PTOPS_OK) return rc;
+  return launch_batches<64>(large, stream);
 }
 
 PTOPS_API size_t ptops_colsum_workspace_bytes(int M, int N) {
@@ -131,7 +247,7 @@ PTOPS_API int ptops_colsum(const float* x, int M, int N, float* out, void* works
   PTOPS_REQUIRE(S <= 65535, "colsum: M=%d exceeds the grid limit", M);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ptops::ceil_div(N, 64), S), dim3(256), 0, stream, x, M, N,
                      (float*)workspace);
-  return ptops_reduce::fold_rows((const float*)workspace, S, N, out, stream);
+  return ptops_reduce::fold_rows((const float*)workspace, S, N, out, stream, true);
 }
 
 

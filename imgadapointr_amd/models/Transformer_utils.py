@@ -120,6 +120,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        ctx.bias_key = bias.data_ptr() if bias is not None else None
         return linear_forward(x, weight, bias)
 
     @staticmethod
@@ -144,6 +145,8 @@ class _LinearFn(torch.autograd.Function):
                 gw = g2.t() @ x2
         if ctx.needs_input_grad[2] and gb is None:
             gb = _native.colsum(g2.contiguous())
+        if gb is not None:
+            _native.fold_returning(ctx.bias_key)       # gb may be a queued fold (include/ptops.h, deferred folds)
         return gx, gw, gb
 
 
@@ -208,6 +211,7 @@ class _LayerNormFn(torch.autograd.Function):
         x2, weight, mean, rstd = ctx.saved_tensors
         C = x2.size(1)
         dx, dgb = _native.layer_norm_backward(gy.contiguous().view(-1, C), x2, mean, rstd, weight)
+        _native.fold_returning(weight.data_ptr())
         return dx.view(gy.shape), dgb[:C], dgb[C:2 * C], None
 
 
@@ -248,6 +252,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         # column sum of this very dx, which the kernel has just accumulated
         _clear_column_sums()
         _offer_column_sums(dx, dgb[2 * C:])
+        _native.fold_returning(weight.data_ptr())
         return dx, dx, dgb[:C], dgb[C:2 * C], None
 
 

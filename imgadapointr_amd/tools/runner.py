@@ -13,6 +13,7 @@ What is different (MI355X-first, results unchanged):
     scalar all-reduces per iteration are one packed all-reduce at log time;
   * datasets of the image / segmentation families are dispatched by the same name rules.
 """
+import contextlib
 import json
 import os
 import time
@@ -20,6 +21,7 @@ import time
 import torch
 import torch.nn as nn
 
+from .. import _native
 from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from ..utils.AverageMeter import AverageMeter
 from ..utils.flat_ddp import FlatDDP
@@ -42,6 +44,9 @@ def unpack_batch(dataset_name, data, device):
     if 'PCN' in dataset_name or dataset_name in ('Completion3D',) or 'ProjectShape' in dataset_name:
         return data[0].to(device), data[1].to(device), ()
     raise NotImplementedError(f'Train phase do not support {dataset_name}')
+
+
+DEFER_FOLDS = os.environ.get("PTOPS_DEFER_FOLDS", "1") != "0"
 
 
 class TrainStep:
@@ -71,7 +76,10 @@ class TrainStep:
         sparse_loss, dense_loss = self.net.get_loss(ret, gt, epoch)
         if self.ddp is not None:            # average only the backward that completes an update
             self.ddp.set_sync(self._num_iter + 1 == self.step_per_update)
-        (sparse_loss + dense_loss).backward()
+        # the first backward after zero_grad hands its gradients over unread (`.grad` is None), so the tiny fold launches
+        # of the bias / LayerNorm gradients can be queued and run batched (include/ptops.h, deferred folds)
+        with (_native.deferred_folds() if (self._num_iter == 0 and DEFER_FOLDS) else contextlib.nullcontext()):
+            (sparse_loss + dense_loss).backward()
         self._num_iter += 1
         if self._num_iter == self.step_per_update:
             self._num_iter = 0

@@ -33,6 +33,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import _native
+
 
 class FlatDDP(nn.Module):
     def __init__(self, module, bucket_mb=64, process_group=None, single_rank_collectives=False):
@@ -102,6 +104,7 @@ class FlatDDP(nn.Module):
     def _pack(self, b):
         """Gather the bucket's gradients into its flat buffer (one multi-tensor copy) and make the
         `.grad`s views of it; a parameter without a gradient contributes zeros."""
+        _native.fold_flush()        # bias / LayerNorm gradients may still be queued folds (tools/runner.py)
         src, dst = [], []
         for p, v in zip(b["params"], b["views"]):
             g = p.grad

@@ -294,6 +294,16 @@ int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const flo
 size_t ptops_colsum_workspace_bytes(int M, int N);
 int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
 
+/* Deferred folds.  ptops_colsum, ptops_layer_norm_backward and ptops_gelu_backward_colsum end with a tiny launch that
+ * adds their partial rows (115 such launches per AdaPoinTr backward, 5.5 us each).  Their results are leaf gradients
+ * (bias / LayerNorm weight gradients) nobody reads before the end of backward, so a training loop may switch
+ * deferral on around backward: the folds are queued and ptops_fold_flush runs all of them in one or two launches,
+ * with the summation order of the immediate launch.  While deferral is on the CALLER must keep every such call's
+ * workspace and output alive and unread until the flush (so give each call its own workspace).
+ * ptops_fold_defer returns the number of folds still queued; switching off does not flush. */
+int ptops_fold_defer(int on);
+int ptops_fold_flush(void* stream);
+
 /* ---------------------------------------------------------- max over tokens --
  * out[b,c] = max_m x[b,m,c], arg[b,c] = the (lowest) token that attains it, for row-major fp32 x [B,M,C]
  * (C % 4 == 0): torch.max(x, dim=1) of the global-feature pools (models/external/AdaPoinTr.py:110,225,

@@ -892,3 +892,47 @@ def test_full_size_properties(native):
     sq = -2 * part @ part.transpose(1, 2) + (part ** 2).sum(-1)[:, :, None] + (part ** 2).sum(-1)[:, None, :]
     kth = sq.topk(k, dim=-1, largest=False).values.max(-1).values
     assert float((kth - dist[..., -1]).abs().max()) < 5e-6
+
+
+def test_deferred_folds_match_immediate_ones(native):
+    """Bias / LayerNorm-weight gradients with their fold launches queued and run batched (`deferred_folds`) are bitwise
+    the gradients of the immediate launches - also for a module applied twice in one graph (the engine adds its two
+    gradients at once, so the queue is flushed at the second one) and for gradients nobody keeps."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(5)
+    lin1, lin2 = TU.Linear(384, 768).cuda(), TU.Linear(768, 384).cuda()
+    norm, act = TU.LayerNorm(384).cuda(), torch.nn.GELU()
+    frozen = TU.LayerNorm(384).cuda().requires_grad_(False)
+    x = torch.randn(8, 576, 384, device="cuda", requires_grad=True)
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(norm.parameters())
+
+    def run(defer):
+        for p in params:
+            p.grad = None
+        h = frozen(x)
+        for _ in range(2):                               # every module is applied twice
+            s, y = TU.add_layer_norm(h, x, norm)
+            h = lin2(TU.gelu(lin1(y), act)) + s
+        loss = h.square().mean()
+        with (native.deferred_folds() if defer else contextlib.nullcontext()):
+            gx, = torch.autograd.grad(loss, x, retain_graph=True)
+            loss.backward()
+        assert not native._fold_keepalive
+        return [gx] + [p.grad.clone() for p in params]
+
+    import contextlib
+    ref, got = run(False), run(True)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # once-applied modules: nothing forces a flush before the end of backward, and the result is still the same
+    def run_once(defer):
+        for p in params:
+            p.grad = None
+        s, y = TU.add_layer_norm(x, x, norm)
+        loss = (lin2(TU.gelu(lin1(y), act)) + s).square().mean()
+        with (native.deferred_folds() if defer else contextlib.nullcontext()):
+            loss.backward()
+        return [p.grad.clone() for p in params]
+
+    for a, b in zip(run_once(False), run_once(True)):
+        assert torch.equal(a, b)
