@@ -25,7 +25,7 @@ def timeit(fn, iters=30):
 
 
 def main():
-    B, H, d = 32, 6, 64
+    B, H, d = int(os.environ.get("ATTN_B", "32")), 6, 64
     torch.manual_seed(0)
     contiguous = os.environ.get("ATTN_LAYOUT", "packed") == "contiguous"    # packed: views of [B,N,3,H,d] as in the model
     for which in sys.argv[1:] or list(SHAPES):

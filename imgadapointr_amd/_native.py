@@ -158,7 +158,7 @@ def _check(t, name, dtype, ndim):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return t if isinstance(t, ctypes.c_void_p) else ctypes.c_void_p(t.data_ptr())
 
 
 def _call(fn_name, *args):
@@ -635,21 +635,34 @@ def fold_flush():
         with torch.cuda.device(dev):
             _call("ptops_fold_flush", ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         _fold_keepalive.clear()
+        for slot in _fold_arena.values():               # stream order: the next producers write after this flush
+            slot[1] = 0
+
+
+_fold_arena = {}              # device index -> [uint8 arena tensor, bump offset]
 
 
 def _fold_workspace(dev, stream, need, *outs):
-    """The workspace of a column-sum producer: the shared per-stream scratch, or - under `deferred_folds` - a buffer of
-    its own that stays alive (with the outputs) until the flush."""
+    """The workspace of a column-sum producer: the shared per-stream scratch, or - under `deferred_folds` - a range
+    of its own in a bump-allocated arena that is recycled at the flush (no tensor is created per call: host time
+    matters for the launch-bound batch-16 models); -> a tensor or a raw device pointer, both accepted by `_ptr`."""
     if not _fold_deferred:
         return _scratch(dev, stream, need)
-    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
-    _fold_keepalive.append(ws)
+    need = (need + 255) & ~255
+    slot = _fold_arena.get(dev.index)
+    if slot is None or slot[1] + need > slot[0].numel():
+        if slot is not None:
+            _fold_keepalive.append(slot[0])             # still referenced by queued folds
+        slot = [torch.empty((max(256 << 20, 2 * need),), dtype=torch.uint8, device=dev), 0]
+        _fold_arena[dev.index] = slot
+    ptr = ctypes.c_void_p(slot[0].data_ptr() + slot[1])
+    slot[1] += need
     for out in outs:
-        # the storage must outlive the queued fold even if autograd drops the gradient, but the tensor object itself
+        # the output's storage must outlive the queued fold even if autograd drops the gradient, but the tensor object
         # must not gain a reference (AccumulateGrad only adopts a gradient it holds the sole reference to - otherwise
-        # it would clone, i.e. READ, the not yet written values): keep a base-less alias of the storage
-        _fold_keepalive.append(torch.empty(0, dtype=out.dtype, device=dev).set_(out.untyped_storage()))
-    return ws
+        # it would clone, i.e. READ, the not yet written values): hold the storage, not the tensor
+        _fold_keepalive.append(out.untyped_storage())
+    return ptr
 
 
 def colsum(x):
