@@ -58,6 +58,10 @@ def _declare(lib):
         "ptops_edge_norm_backward": (c_int, [P] * 10 + [c_int] * 6 + [ctypes.c_float] + [P] * 5),
         "ptops_colsum_workspace_bytes": (c_size, [c_int, c_int]),
         "ptops_colsum": (c_int, [P, c_int, c_int, P, P, P]),
+        "ptops_adamw_row_bytes": (c_int, []),
+        "ptops_adamw_chunk_elements": (c_int, []),
+        "ptops_adamw_clip_step": (c_int, [P, c_int, P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                          P, P, P]),
         "ptops_fold_defer": (c_int, [c_int]),
         "ptops_fold_flush": (c_int, [P]),
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
@@ -98,7 +102,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
-    "ptops_fold_defer", "ptops_fold_flush",
+    "ptops_fold_defer", "ptops_fold_flush", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
     "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
@@ -750,6 +754,13 @@ def gemm_split3_wgrad(dy, x, want_bias=False):
         _call("ptops_gemm_f32_split3_wgrad", _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dw), dw.stride(0),
               _ptr(db) if db is not None else None, _ptr(ws), need, _stream(dy))
     return dw, db
+
+
+def adamw_clip_step(rows_dev, n_tensors, chunks_dev, n_chunks, max_norm, beta1, beta2, eps, partial, norm_coef):
+    """Gradient-norm clipping + AdamW over the device tables of utils/clip_adamw.py (csrc/optimizer.hip)."""
+    with torch.cuda.device(rows_dev.device):
+        _call("ptops_adamw_clip_step", _ptr(rows_dev), int(n_tensors), _ptr(chunks_dev), int(n_chunks), float(max_norm),
+              float(beta1), float(beta2), float(eps), _ptr(partial), _ptr(norm_coef), _stream(rows_dev))
 
 
 def _scratch(dev, stream, need):

@@ -47,6 +47,7 @@ def unpack_batch(dataset_name, data, device):
 
 
 DEFER_FOLDS = os.environ.get("PTOPS_DEFER_FOLDS", "1") != "0"
+FUSED_CLIP_ADAMW = os.environ.get("PTOPS_FUSED_ADAMW", "1") != "0"
 
 
 class TrainStep:
@@ -85,8 +86,11 @@ class TrainStep:
             self._num_iter = 0
             if self.ddp is not None:
                 self.ddp.finalize()
-            torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.clip, norm_type=2)
-            self.optimizer.step()
+            if hasattr(self.optimizer, "step_clipped") and FUSED_CLIP_ADAMW:
+                self.optimizer.step_clipped(self.clip)          # clip + AdamW of all parameters, three launches
+            else:
+                torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.clip, norm_type=2)
+                self.optimizer.step()
             self.zero_grad()
         return sparse_loss.detach(), dense_loss.detach()
 

@@ -1,0 +1,122 @@
+"""AdamW + global gradient-norm clipping for all parameters in three kernel launches (csrc/optimizer.hip).
+
+`ClipAdamW` IS a `torch.optim.AdamW` (same constructor, param groups, state keys `step` / `exp_avg` / `exp_avg_sq`, so
+checkpoints and LR schedulers are unaffected); it adds `step_clipped(max_norm)`, which does what the reference's
+`clip_grad_norm_(params, max_norm, 2)` followed by `optimizer.step()` does (tools/runner.py:208-212) — except that the
+gradients themselves are left unscaled (the coefficient is applied on the fly; they are dropped right afterwards).
+Parameters that are not fp32 CUDA tensors with dense contiguous gradients send the whole step down the stock path."""
+import numpy as np
+import torch
+
+from .. import _native
+
+_ROW = 64      # bytes per tensor row of the device table (ptops_adamw_row_bytes)
+
+
+class ClipAdamW(torch.optim.AdamW):
+    def __init__(self, params, **kwargs):
+        kwargs.pop("fused", None)
+        super().__init__(params, **kwargs)
+        self._plan = None
+        self._ring = 0
+
+    # ------------------------------------------------------------------ stock path (CPU tensors, exotic gradients)
+    def _stock(self, max_norm):
+        params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        norm = torch.nn.utils.clip_grad_norm_(params, max_norm, norm_type=2) if max_norm and max_norm > 0 and params else None
+        super().step()
+        return norm
+
+    def _supported(self, params):
+        if not params or _native.backend_for_testing() is not None:
+            return False
+        dev = params[0].device
+        if not self.uniform_hyperparameters():
+            return False
+        for g in self.param_groups:
+            if g.get("amsgrad") or g.get("maximize") or g.get("capturable"):
+                return False
+        return all(p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous()
+                   and p.grad.dtype == torch.float32 and not p.grad.is_sparse and p.grad.is_contiguous()
+                   and p.grad.device == dev for p in params)
+
+    # ------------------------------------------------------------------ the plan: everything that does not change per step
+    def _make_plan(self, params, group_of):
+        dev = params[0].device
+        n = len(params)
+        chunk = int(_native.load().ptops_adamw_chunk_elements())
+        assert int(_native.load().ptops_adamw_row_bytes()) == _ROW
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        rows = np.zeros((n, _ROW // 8), dtype=np.uint64)                 # 8 x 8 bytes per row
+        rows[:, 0] = [p.data_ptr() for p in params]
+        rows[:, 2] = [self.state[p]["exp_avg"].data_ptr() for p in params]
+        rows[:, 3] = [self.state[p]["exp_avg_sq"].data_ptr() for p in params]
+        numel = np.array([p.numel() for p in params], dtype=np.int64)
+        rows[:, 4] = numel.view(np.uint64)
+        counts = (numel + chunk - 1) // chunk
+        tensor_of = np.repeat(np.arange(n, dtype=np.int32), counts)
+        first = np.cumsum(counts) - counts
+        offset = (np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(first, counts)) * chunk
+        chunks = np.zeros((len(tensor_of), 2), dtype=np.int64)
+        chunks[:, 0] = tensor_of.astype(np.int64)                        # int32 tensor index + int32 zero padding
+        chunks[:, 1] = offset
+        plan = {
+            "key": tuple(id(p) for p in params), "params": params, "group_of": np.asarray(group_of), "rows": rows,
+            "n_chunks": len(tensor_of),
+            "chunks_dev": torch.from_numpy(chunks.view(np.uint8).reshape(-1)).to(dev),
+            "rows_dev": torch.empty(n * _ROW, dtype=torch.uint8, device=dev),
+            # pinned staging buffers in a ring: an async copy may still be reading the one of the previous steps
+            "rows_host": [torch.empty(n * _ROW, dtype=torch.uint8).pin_memory() for _ in range(4)],
+            "partial": torch.empty(len(tensor_of), dtype=torch.float32, device=dev),
+            "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
+        }
+        return plan
+
+    @torch.no_grad()
+    def step_clipped(self, max_norm):
+        """clip_grad_norm_(all parameters with a gradient, max_norm) + step().  -> the gradient norm (0-dim tensor)."""
+        params, group_of = [], []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if p.grad is not None:
+                    params.append(p)
+                    group_of.append(gi)
+        if not self._supported(params):
+            return self._stock(max_norm)
+        key = tuple(id(p) for p in params)
+        if self._plan is None or self._plan["key"] != key:
+            self._plan = self._make_plan(params, group_of)
+        plan = self._plan
+        rows = plan["rows"]
+        rows[:, 1] = [p.grad.data_ptr() for p in params]
+        steps = np.empty(len(params), dtype=np.float64)
+        for i, p in enumerate(params):
+            st = self.state[p]["step"]
+            st += 1
+            steps[i] = float(st)
+        beta1, beta2 = self.param_groups[0]["betas"]
+        eps = self.param_groups[0]["eps"]
+        lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float32)[plan["group_of"]]
+        wd = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float32)[plan["group_of"]]
+        f32 = rows.view(np.float32).reshape(len(params), _ROW // 4)
+        f32[:, 10] = lr
+        f32[:, 11] = wd
+        f32[:, 12] = (1.0 - beta1 ** steps).astype(np.float32)
+        f32[:, 13] = np.sqrt(1.0 - beta2 ** steps).astype(np.float32)
+        host = plan["rows_host"][self._ring]
+        self._ring = (self._ring + 1) % len(plan["rows_host"])
+        host.numpy()[:] = rows.view(np.uint8).reshape(-1)
+        plan["rows_dev"].copy_(host, non_blocking=True)
+        _native.adamw_clip_step(plan["rows_dev"], len(params), plan["chunks_dev"], plan["n_chunks"],
+                                float(max_norm) if max_norm else 0.0, beta1, beta2, eps, plan["partial"], plan["norm_coef"])
+        return plan["norm_coef"][0]
+
+    def uniform_hyperparameters(self):
+        """betas / eps must be the same in every group for the fused path (they are kernel arguments)."""
+        b, e = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        return all(g["betas"] == b and g["eps"] == e for g in self.param_groups)

@@ -334,6 +334,22 @@ int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, 
                                 float* dW, long long lddw, float* db, void* workspace, long long workspace_bytes,
                                 void* stream);
 
+/* ------------------------------------------------------------------- clip + AdamW --
+ * torch.nn.utils.clip_grad_norm_(params, max_norm, 2) followed by torch.optim.AdamW.step() (tools/runner.py:208-212,
+ * tools/builder.py:37-52) for ALL parameters in three launches: |g|^2 per 4096-element chunk, the norm and the clip
+ * coefficient min(1, max_norm / (norm + 1e-6)), the update (decoupled weight decay, lerp / addcmul moments,
+ * bias-corrected step; the arithmetic of torch/optim/adamw.py::_single_tensor_adamw in fp32).  The gradients are read,
+ * not scaled in place.
+ * rows: device table of n_tensors rows of ptops_adamw_row_bytes() = 64 bytes {float* param, const float* grad,
+ * float* exp_avg, float* exp_avg_sq, int64 numel, float lr, float weight_decay, float 1 - beta1^step,
+ * float sqrt(1 - beta2^step), 8 bytes padding}; chunks: device table of n_chunks rows {int32 tensor, int32 0,
+ * int64 offset}, one per started ptops_adamw_chunk_elements() of every tensor; partial: n_chunks floats of scratch;
+ * norm_coef: 2 floats out = {gradient norm before clipping, coefficient applied}.  max_norm <= 0: no clipping. */
+int ptops_adamw_row_bytes(void);
+int ptops_adamw_chunk_elements(void);
+int ptops_adamw_clip_step(const void* rows, int n_tensors, const void* chunks, int n_chunks, float max_norm, float beta1,
+                          float beta2, float eps, float* partial, float* norm_coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

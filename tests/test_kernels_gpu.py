@@ -936,3 +936,50 @@ def test_deferred_folds_match_immediate_ones(native):
 
     for a, b in zip(run_once(False), run_once(True)):
         assert torch.equal(a, b)
+
+
+def test_clip_adamw_matches_torch(native):
+    """ClipAdamW.step_clipped == clip_grad_norm_ + torch.optim.AdamW.step over several steps: two weight-decay groups,
+    an lr change, a parameter without gradient on some steps, tensor sizes around the 4096-element chunk, clipping
+    active and inactive; state keys stay torch's (checkpoint compatible)."""
+    from imgadapointr_amd.utils.clip_adamw import ClipAdamW
+    torch.manual_seed(3)
+    shapes = [(384, 384), (384,), (1,), (4096,), (4097,), (1152, 384), (3, 5, 7), (8192 + 5,)]
+    ref_p = [torch.randn(*s, device="cuda").requires_grad_(True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+
+    def groups(ps):
+        return [{"params": [p for p in ps if p.dim() == 1], "weight_decay": 0.0},
+                {"params": [p for p in ps if p.dim() != 1], "weight_decay": 5e-2}]
+
+    ref = torch.optim.AdamW(groups(ref_p), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    our = ClipAdamW(groups(our_p), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(6):
+        scale = 100.0 if it % 2 == 0 else 1e-3                    # clipping active / inactive (max_norm = 10)
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 2 and it in (1, 4):
+                a.grad = b.grad = None                            # a parameter that is skipped now and then
+                continue
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        if it == 3:
+            for o in (ref, our):
+                for grp in o.param_groups:
+                    grp["lr"] = 3e-3
+        with_grad = [p for p in ref_p if p.grad is not None]
+        want_norm = torch.nn.utils.clip_grad_norm_(with_grad, 10.0, norm_type=2)
+        ref.step()
+        got_norm = our.step_clipped(10.0)
+        assert abs(float(got_norm) - float(want_norm)) <= 1e-5 * float(want_norm)
+        for a, b in zip(ref_p, our_p):
+            # a few ulp of the largest elements: the norm (hence the clip coefficient) is summed in another order
+            tol = 8 * 2.0 ** -24 * float(a.detach().abs().max()) + 1e-7
+            assert float((a.detach() - b.detach()).abs().max()) <= tol, (it, a.shape, float((a - b).abs().max()))
+    for a, b in zip(ref_p, our_p):
+        sa, sb = ref.state[a], our.state[b]
+        assert set(sa) == set(sb) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == float(sb["step"])
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-5, atol=1e-6)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-5, atol=1e-8)
+    # a state_dict round trip through the stock class
+    other = torch.optim.AdamW(groups([p.detach().clone().requires_grad_(True) for p in our_p]), lr=1e-2)
+    other.load_state_dict(our.state_dict())

@@ -156,3 +156,25 @@ def test_average_meter_weighted_update_is_the_per_iteration_mean():
         windowed.update([sum(w) / len(w)], n=len(w))
     assert abs(windowed.avg(0) - per_iter.avg(0)) < 1e-12
     assert windowed.count(0) == 11 and windowed.val(0) == sum(vals[6:]) / 5
+
+
+def test_clip_adamw_host_path_matches_torch():
+    """ClipAdamW on CPU parameters (no device kernels) takes the stock path: clip_grad_norm_ + torch's AdamW step,
+    same state keys, and its plain step() is torch's."""
+    import torch
+    from imgadapointr_amd.utils.clip_adamw import ClipAdamW
+    torch.manual_seed(0)
+    a = [torch.randn(5, 7, requires_grad=True), torch.randn(7, requires_grad=True)]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    ref = torch.optim.AdamW([{"params": [a[1]], "weight_decay": 0.0}, {"params": [a[0]], "weight_decay": 1e-2}], lr=1e-2)
+    our = ClipAdamW([{"params": [b[1]], "weight_decay": 0.0}, {"params": [b[0]], "weight_decay": 1e-2}], lr=1e-2)
+    for _ in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p) * 50
+            p.grad, q.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_(a, 10.0)
+        ref.step()
+        our.step_clipped(10.0)
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+        assert set(our.state[q]) == {"step", "exp_avg", "exp_avg_sq"}
