@@ -30,7 +30,7 @@ FAMILIES = [
     ("conv (MIOpen)", r"conv|Conv|igemm|miopen"),
     ("norm", r"layer_norm|LayerNorm|group_norm|GroupNorm|RowwiseMoments|batch_norm|BatchNorm"),
     ("reduce", r"reduce_kernel|Reduce"),
-    ("optimizer", r"multi_tensor_apply"),
+    ("optimizer", r"multi_tensor_apply|adamw_"),
     ("copy / cat / fill", r"CatArray|copy|Copy|fill|Fill|memcpy|memset"),
     ("sort / scatter / index", r"sort|Sort|scatter|index_|gather"),
     ("elementwise", r"elementwise|vectorized"),
