@@ -67,6 +67,8 @@ def _declare(lib):
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
         "ptops_gemm_f32_split3": (c_int, [P, ctypes.c_longlong, c_int, P, ctypes.c_longlong, c_int, P, ctypes.c_longlong,
                                           c_int, c_int, c_int, P, P]),
+        "ptops_gemm_f32_split3_gelu": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, P, ctypes.c_longlong, P,
+                                               ctypes.c_longlong, c_int, c_int, c_int, P, P]),
         "ptops_gemm_f32_split3_wgrad_workspace": (ctypes.c_longlong, [c_int, c_int, c_int]),
         "ptops_gemm_f32_split3_wgrad": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, c_int, c_int, c_int, P,
                                                 ctypes.c_longlong, P, P, ctypes.c_longlong, P]),
@@ -104,7 +106,7 @@ EXPORTS = (
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_fold_defer", "ptops_fold_flush", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
-    "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad",
+    "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad", "ptops_gemm_f32_split3_gelu",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
@@ -733,6 +735,26 @@ def gemm_split3(a, b, bias=None, a_k_contiguous=True, b_k_contiguous=True, out=N
         _call("ptops_gemm_f32_split3", _ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous),
               _ptr(out), out.stride(0), M, N, K, _ptr(bias) if bias is not None else None, _stream(a))
     return out
+
+
+def gemm_split3_gelu(x, w, bias=None):
+    """(x . w^T + bias, gelu of it) from one launch; x [M,K], w [N,K] fp32 with unit inner stride, K % 16 == 0."""
+    for name, t in (("x", x), ("w", w)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise ValueError(f"gemm_split3_gelu: {name} must be a 2-D fp32 CUDA tensor with unit inner stride")
+    _same_device(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm_split3_gelu: inner sizes differ ({K} vs {w.shape[1]})")
+    with torch.cuda.device(x.device):
+        u = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        g = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        if bias is not None:
+            _check(bias, "bias", torch.float32, 1)
+        _call("ptops_gemm_f32_split3_gelu", _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(u), u.stride(0), _ptr(g),
+              g.stride(0), M, N, K, _ptr(bias) if bias is not None else None, _stream(x))
+    return u, g
 
 
 def gemm_split3_wgrad(dy, x, want_bias=False):

@@ -32,7 +32,8 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;   // [N] or null
-  long long lda, ldb, ldc;
+  float* G;            // optional second output: gelu(C) (exact erf form), leading dimension ldg
+  long long lda, ldb, ldc, ldg;
   int M, N, K;
   int tiles_n;
 };
@@ -171,7 +172,12 @@ __global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m < g.M) g.C[(long long)m * g.ldc + n] = acc[j][r] + bv;
+      if (m < g.M) {
+        const float u = acc[j][r] + bv;
+        g.C[(long long)m * g.ldc + n] = u;
+        // nn.GELU() of the pre-activation in the same pass (x * 0.5 * (1 + erf(x / sqrt 2)), as aten's kernel)
+        if (g.G) g.G[(long long)m * g.ldg + n] = (u * 0.5f) * (1.0f + erff(u * 0.70710678118654752440f));
+      }
     }
   }
 }
@@ -306,10 +312,9 @@ static int wgrad_splits(int M, int N, int K) {
 
 // C[M,N] = opA . opB^T + bias.  a_k_contiguous: A is stored [M, lda] (k contiguous) else [K, lda] (m contiguous);
 // b_k_contiguous: B is stored [N, ldb] else [K, ldb].  K % 16 == 0; a k-contiguous operand needs 16-byte aligned rows.
-PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
-                                    int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
-                                    void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int gemm_split3_launch(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
+                              int b_k_contiguous, float* C, long long ldc, float* G, long long ldg, int M, int N, int K,
+                              const float* bias, hipStream_t stream) {
   PTOPS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_f32_split3: negative size");
   if (M == 0 || N == 0) return PTOPS_OK;
   PTOPS_REQUIRE(A && B && C, "gemm_f32_split3: null pointer");
@@ -317,8 +322,8 @@ PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_conti
   if (a_k_contiguous) PTOPS_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0, "gemm_f32_split3: A rows must be 16-byte aligned");
   if (b_k_contiguous) PTOPS_REQUIRE(ldb % 4 == 0 && ((uintptr_t)B & 15) == 0, "gemm_f32_split3: B rows must be 16-byte aligned");
   GemmArgs g;
-  g.A = A, g.B = B, g.C = C, g.bias = bias;
-  g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+  g.A = A, g.B = B, g.C = C, g.bias = bias, g.G = G;
+  g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldg = ldg;
   g.M = M, g.N = N, g.K = K;
   g.tiles_n = ptops::ceil_div(N, kBN);
   const long long blocks = (long long)ptops::ceil_div(M, kBM) * g.tiles_n;
@@ -329,6 +334,22 @@ PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_conti
   else if (b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, block, 0, stream, g);
   return ptops::check_launch("gemm_split3_kernel");
+}
+
+PTOPS_API int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, const float* B, long long ldb,
+                                    int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
+                                    void* stream) {
+  return gemm_split3_launch(A, lda, a_k_contiguous, B, ldb, b_k_contiguous, C, ldc, nullptr, 0, M, N, K, bias,
+                            (hipStream_t)stream);
+}
+
+// Forward of Linear + nn.GELU(): C = A . B^T + bias (the pre-activation, kept for backward) and G = gelu(C) from the
+// same epilogue (A [M, lda], B [N, ldb], both k contiguous).
+PTOPS_API int ptops_gemm_f32_split3_gelu(const float* A, long long lda, const float* B, long long ldb, float* C,
+                                         long long ldc, float* G, long long ldg, int M, int N, int K, const float* bias,
+                                         void* stream) {
+  PTOPS_REQUIRE(G != nullptr || M == 0 || N == 0, "gemm_f32_split3_gelu: null output");
+  return gemm_split3_launch(A, lda, 1, B, ldb, 1, C, ldc, G, ldg, M, N, K, bias, (hipStream_t)stream);
 }
 
 PTOPS_API long long ptops_gemm_f32_split3_wgrad_workspace(int M, int N, int K) {

@@ -126,28 +126,67 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
-        g2 = grad.reshape(-1, grad.size(-1))
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            if g2.is_contiguous() and _use_split3_dgrad(g2, weight):
-                gx = _native.gemm_split3(g2, weight, None, True, False).view(x.shape)
-            else:
-                gx = (g2 @ weight).view(x.shape)
-        if ctx.needs_input_grad[2]:
-            gb = _take_column_sums(grad)
-        if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.size(-1))
-            if _use_split3_wgrad(g2, x2):
-                # the bias gradient (column sums of g2) falls out of the same pass
-                gw, db = _native.gemm_split3_wgrad(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
-                gb = db if db is not None else gb
-            else:
-                gw = g2.t() @ x2
-        if ctx.needs_input_grad[2] and gb is None:
-            gb = _native.colsum(g2.contiguous())
-        if gb is not None:
-            _native.fold_returning(ctx.bias_key)       # gb may be a queued fold (include/ptops.h, deferred folds)
-        return gx, gw, gb
+        return _linear_backward(ctx, x, weight, grad, _take_column_sums(grad) if ctx.needs_input_grad[2] else None)
+
+
+def _linear_backward(ctx, x, weight, grad, gb):
+    """(dx, dW, db) of y = x W^T + b for the gradient `grad` of y; `gb`: column sums of `grad` if a producer kernel
+    already has them."""
+    g2 = grad.reshape(-1, grad.size(-1))
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+        if g2.is_contiguous() and _use_split3_dgrad(g2, weight):
+            gx = _native.gemm_split3(g2, weight, None, True, False).view(x.shape)
+        else:
+            gx = (g2 @ weight).view(x.shape)
+    if ctx.needs_input_grad[1]:
+        x2 = x.reshape(-1, x.size(-1))
+        if _use_split3_wgrad(g2, x2):
+            # the bias gradient (column sums of g2) falls out of the same pass
+            gw, db = _native.gemm_split3_wgrad(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
+            gb = db if db is not None else gb
+        else:
+            gw = g2.t() @ x2
+    if ctx.needs_input_grad[2] and gb is None:
+        gb = _native.colsum(g2.contiguous())
+    if not ctx.needs_input_grad[2]:
+        gb = None
+    if gb is not None:
+        _native.fold_returning(ctx.bias_key)       # gb may be a queued fold (include/ptops.h, deferred folds)
+    return gx, gw, gb
+
+
+FUSED_LINEAR_GELU = os.environ.get("PTOPS_FUSED_LINEAR_GELU", "1") != "0"
+
+
+class _LinearGeluFn(torch.autograd.Function):
+    """gelu(x W^T + b) for the first layer of an Mlp when that GEMM runs on the split-bf16 kernel: the GELU comes out of
+    the GEMM's epilogue next to the pre-activation (one launch and one read of the pre-activation less), the backward is
+    the fused GELU-backward + column-sum kernel followed by the Linear backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        u, g = _native.gemm_split3_gelu(x.view(-1, x.size(-1)), weight, bias)
+        ctx.save_for_backward(x, weight, u)
+        ctx.bias_key = bias.data_ptr() if bias is not None else None
+        return g.view(*x.shape[:-1], weight.size(0))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, u = ctx.saved_tensors
+        N = u.size(1)
+        dpre, cs = _native.gelu_backward_colsum(u, gy.contiguous().view(-1, N))
+        return _linear_backward(ctx, x, weight, dpre.view(*x.shape[:-1], N), cs if ctx.needs_input_grad[2] else None)
+
+
+def linear_gelu(lin, act, x):
+    """act(lin(x)) for an nn.Linear-like `lin` and an nn.GELU() `act`."""
+    if (FUSED_LINEAR_GELU and FUSED_GELU_BACKWARD and isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none"
+            and FAST_BIAS_GRAD and x.is_cuda and x.dim() >= 2 and x.is_contiguous() and torch.is_grad_enabled()
+            and (x.requires_grad or lin.weight.requires_grad) and lin.bias is not None and lin.weight.size(0) % 4 == 0
+            and _use_split3_forward(x.view(-1, x.size(-1)), lin.weight)):
+        return _LinearGeluFn.apply(x, lin.weight, lin.bias)
+    return gelu(lin(x), act)
 
 
 FAST_BIAS_GRAD = True
@@ -418,7 +457,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(gelu(self.fc1(x), self.act))))
+        return self.drop(self.fc2(self.drop(linear_gelu(self.fc1, self.act, x))))
 
 
 def _block_bias(nq, nk, split_q, limit_k, device):

@@ -324,6 +324,11 @@ int ptops_gemm_f32_split3(const float* A, long long lda, int a_k_contiguous, con
                           int b_k_contiguous, float* C, long long ldc, int M, int N, int K, const float* bias,
                           void* stream);
 
+/* Linear + nn.GELU() forward in one pass (Mlp.fc1 + act, models/Transformer_utils.py:146-159): C = A . B^T + bias is the
+ * pre-activation the backward needs, G = gelu(C) (exact erf form) comes out of the same epilogue. */
+int ptops_gemm_f32_split3_gelu(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc,
+                               float* G, long long ldg, int M, int N, int K, const float* bias, void* stream);
+
 /* Weight gradient of the same layers: dW[N,K] = dY[M,N]^T . X[M,K] and, when db != NULL, db[N] = the column sums of dY
  * (the bias gradient; the rows of dY pass through the staging registers anyway).  The long contraction (M rows) is
  * split over several workgroups per 128 x 128 output tile, whose partial products go to `workspace` and are added in

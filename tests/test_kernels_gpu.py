@@ -983,3 +983,31 @@ def test_clip_adamw_matches_torch(native):
     # a state_dict round trip through the stock class
     other = torch.optim.AdamW(groups([p.detach().clone().requires_grad_(True) for p in our_p]), lr=1e-2)
     other.load_state_dict(our.state_dict())
+
+
+def test_mlp_with_gelu_in_the_gemm_epilogue(native):
+    """Mlp whose fc1 + GELU is one GEMM launch (GELU from the epilogue) against the unfused path: same outputs to fp32
+    rounding, same gradients; and the epilogue GELU against float64."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(9)
+    mlp = TU.Mlp(384, 768).cuda()
+    x = torch.randn(32, 576, 384, device="cuda", requires_grad=True)
+    gy = torch.randn(32, 576, 384, device="cuda")
+    res = {}
+    for fused in (True, False):
+        TU.FUSED_LINEAR_GELU = fused
+        mlp.zero_grad()
+        y = mlp(x)
+        gx, = torch.autograd.grad(y, x, gy, retain_graph=True)
+        y.backward(gy)
+        res[fused] = [y.detach(), gx] + [p.grad.clone() for p in mlp.parameters()]
+    TU.FUSED_LINEAR_GELU = True
+    for a, b in zip(res[True], res[False]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale, float((a - b).abs().max()) / scale
+    u, g = native.gemm_split3_gelu(x.detach().view(-1, 384), mlp.fc1.weight.detach(), mlp.fc1.bias.detach())
+    ref_u = x.detach().view(-1, 384)[:2048].double() @ mlp.fc1.weight.detach().double().t() + mlp.fc1.bias.detach().double()
+    ref_g = torch.nn.functional.gelu(ref_u)
+    assert float((u[:2048].double() - ref_u).abs().max()) < 2e-6 * float(ref_u.abs().max())
+    assert float((g[:2048].double() - ref_g).abs().max()) < 2e-6 * float(ref_g.abs().max())
+    assert torch.equal(g, torch.nn.functional.gelu(u))          # the epilogue's GELU is aten's, bit for bit
