@@ -20,6 +20,15 @@ class ClipAdamW(torch.optim.AdamW):
         self._plan = None
         self._ring = 0
 
+    # the plan caches the addresses of the moment tensors: anything that may replace them drops it
+    def load_state_dict(self, state_dict):
+        self._plan = None
+        return super().load_state_dict(state_dict)
+
+    def add_param_group(self, param_group):
+        self._plan = None
+        return super().add_param_group(param_group)
+
     # ------------------------------------------------------------------ stock path (CPU tensors, exotic gradients)
     def _stock(self, max_norm):
         params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
@@ -89,7 +98,8 @@ class ClipAdamW(torch.optim.AdamW):
         if not self._supported(params):
             return self._stock(max_norm)
         key = tuple(id(p) for p in params)
-        if self._plan is None or self._plan["key"] != key:
+        if (self._plan is None or self._plan["key"] != key
+                or any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(params[:4], self._plan["rows"][:4, 2]))):
             self._plan = self._make_plan(params, group_of)
         plan = self._plan
         rows = plan["rows"]

@@ -1011,3 +1011,23 @@ def test_mlp_with_gelu_in_the_gemm_epilogue(native):
     assert float((u[:2048].double() - ref_u).abs().max()) < 2e-6 * float(ref_u.abs().max())
     assert float((g[:2048].double() - ref_g).abs().max()) < 2e-6 * float(ref_g.abs().max())
     assert torch.equal(g, torch.nn.functional.gelu(u))          # the epilogue's GELU is aten's, bit for bit
+
+
+def test_clip_adamw_survives_a_state_dict_round_trip(native):
+    """load_state_dict replaces the moment tensors: the cached device table must follow them."""
+    from imgadapointr_amd.utils.clip_adamw import ClipAdamW
+    torch.manual_seed(4)
+    a = [torch.randn(300, 40, device="cuda", requires_grad=True), torch.randn(40, device="cuda", requires_grad=True)]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    ref, our = torch.optim.AdamW(a, lr=1e-2), ClipAdamW(b, lr=1e-2)
+    for it in range(4):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_norm_(a, 1.0)
+        ref.step()
+        our.step_clipped(1.0)
+        if it == 1:
+            our.load_state_dict(our.state_dict())
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max()) + 1e-7
