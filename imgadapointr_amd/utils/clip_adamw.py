@@ -81,6 +81,7 @@ class ClipAdamW(torch.optim.AdamW):
             "rows_dev": torch.empty(n * _ROW, dtype=torch.uint8, device=dev),
             # pinned staging buffers in a ring: an async copy may still be reading the one of the previous steps
             "rows_host": [torch.empty(n * _ROW, dtype=torch.uint8).pin_memory() for _ in range(4)],
+            "rows_event": [None] * 4,
             "partial": torch.empty(len(tensor_of), dtype=torch.float32, device=dev),
             "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
         }
@@ -118,10 +119,16 @@ class ClipAdamW(torch.optim.AdamW):
         f32[:, 11] = wd
         f32[:, 12] = (1.0 - beta1 ** steps).astype(np.float32)
         f32[:, 13] = np.sqrt(1.0 - beta2 ** steps).astype(np.float32)
-        host = plan["rows_host"][self._ring]
+        slot = self._ring
         self._ring = (self._ring + 1) % len(plan["rows_host"])
+        host = plan["rows_host"][slot]
+        if plan["rows_event"][slot] is not None:
+            plan["rows_event"][slot].synchronize()      # the copy that read this buffer four steps ago (long done)
         host.numpy()[:] = rows.view(np.uint8).reshape(-1)
         plan["rows_dev"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        plan["rows_event"][slot] = ev
         _native.adamw_clip_step(plan["rows_dev"], len(params), plan["chunks_dev"], plan["n_chunks"],
                                 float(max_norm) if max_norm else 0.0, beta1, beta2, eps, plan["partial"], plan["norm_coef"])
         return plan["norm_coef"][0]
