@@ -196,6 +196,68 @@ class AttentionProbe:
         return out
 
 
+class GemmProbe:
+    """Events around every dense-layer GEMM that runs on libptops' split-bf16 kernels during one timed step (forward,
+    input gradient, weight gradient incl. its reduction, Linear + GELU): fp32 product FLOPs per second (`achieved`) and
+    the executed bf16 piece-product FLOPs (x 6) against the dense bf16 peak (`frac`).  The remaining GEMMs of the step are
+    hipBLASLt / rocBLAS fp32-MFMA kernels (profiles/round2/step_breakdown_v4.txt)."""
+    NAMES = ("gemm_split3", "gemm_split3_wgrad", "gemm_split3_gelu")
+
+    def __init__(self):
+        self.orig = {n: getattr(_native, n) for n in self.NAMES}
+        self.enabled = False
+        self.rec = []
+        for n in self.NAMES:
+            setattr(_native, n, self._wrap(n))
+
+    def _wrap(self, name):
+        fn = self.orig[name]
+
+        def call(*args, **kw):
+            if not self.enabled:
+                return fn(*args, **kw)
+            a, b = args[0], args[1]
+            if name == "gemm_split3_wgrad":                       # dy [M,N], x [M,K] -> [N,K]
+                flops = 2.0 * a.shape[0] * a.shape[1] * b.shape[1]
+            else:
+                ak = kw.get("a_k_contiguous", args[3] if len(args) > 3 else True) if name == "gemm_split3" else True
+                bk = kw.get("b_k_contiguous", args[4] if len(args) > 4 else True) if name == "gemm_split3" else True
+                M, K = (a.shape[0], a.shape[1]) if ak else (a.shape[1], a.shape[0])
+                N = b.shape[0] if bk else b.shape[1]
+                flops = 2.0 * M * N * K
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*args, **kw)
+            e.record()
+            self.rec.append((name, s, e, flops))
+            return out
+        return call
+
+    def restore(self):
+        for n in self.NAMES:
+            setattr(_native, n, self.orig[n])
+
+    def summary(self):
+        out = {"bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+               "note": "dense-layer GEMMs on the split-bf16 kernels in one timed step; achieved = fp32 product FLOP/s, "
+                       "executed = x 6 (six bf16 piece products per fp32 product), frac = executed / dense bf16 peak"}
+        by = {}
+        for name, s, e, fl in self.rec:
+            d = by.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += fl
+        tot_ms = sum(d[1] for d in by.values())
+        tot_fl = sum(d[2] for d in by.values())
+        for name, (n, ms, fl) in by.items():
+            out[name] = {"launches_per_step": n, "ms_per_step": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 1)}
+        if tot_ms > 0:
+            out.update({"ms_per_step": round(tot_ms, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                        "executed": round(6 * tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                        "frac": round(6 * tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+        return out
+
+
 class PrimitiveProbe:
     """Events around every FPS and kNN launch of one step (algorithmic bytes 12 N + 4 npoint resp.
     12 (N + S) + 4 S k per cloud; work = (npoint - 1) N point updates resp. S N pair evaluations).  Both are
@@ -344,6 +406,7 @@ def main():
     _native.attention_forward, _native.attention_backward = aprobe.forward, aprobe.backward
     pprobe = PrimitiveProbe()
     _native.furthest_point_sample, _native.knn = pprobe.furthest_point_sample, pprobe.knn_call
+    gprobe = GemmProbe()
 
     def barrier():
         if world > 1 or single_rank_rccl:
@@ -362,12 +425,12 @@ def main():
             note("first step done")
     barrier()
     note("timed region")
-    probe.enabled = aprobe.enabled = pprobe.enabled = True
+    probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = True
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
         last = step(partial, gt)
-        aprobe.enabled = pprobe.enabled = False   # ~150 timing events per step cost ~1 ms: only the first timed step carries them
+        aprobe.enabled = pprobe.enabled = gprobe.enabled = False   # ~270 timing events per step cost ~1 ms: only the first timed step carries them
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
@@ -375,6 +438,7 @@ def main():
     _native.chamfer_forward = probe.orig
     _native.attention_forward, _native.attention_backward = aprobe.fwd, aprobe.bwd
     _native.furthest_point_sample, _native.knn = pprobe.fps, pprobe.knn
+    gprobe.restore()
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -392,8 +456,8 @@ def main():
             "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
                                    f"bs={B}/GPU, full train step (BASELINE configs[1])",
                        "global_batch": world * B, "parallelism": f"dp{world}", "gemm_selection": gemm,
-                       "gemm_arithmetic": ("fp32 in / fp32 out everywhere; Linear forward + input-gradient GEMMs with >= 16384 rows "
-                                           "run on libptops' split-bf16 kernel (three bf16 pieces per operand, six exact piece "
+                       "gemm_arithmetic": ("fp32 in / fp32 out everywhere; Linear forward, input-gradient and the larger weight-gradient "
+                                           "GEMMs with >= 16384 rows run on libptops' split-bf16 kernels (three bf16 pieces per operand, six exact piece "
                                            "products, fp32 accumulation: error vs float64 <= the fp32 MFMA library kernels, "
                                            "tests/test_kernels_gpu.py::test_gemm_split3_is_fp32_accurate); PTOPS_SPLIT3_GEMM=0 "
                                            "keeps all GEMMs on hipBLASLt / rocBLAS fp32 MFMA (+0.8 ms per step)")
@@ -402,6 +466,7 @@ def main():
             "last_losses_x1000": {"denoise": round(losses[0], 4), "recon": round(losses[1], 4)},
             "roofline": probe.summary(),
             "roofline_attention": aprobe.summary(1),
+            "roofline_gemm": gprobe.summary(),
             "roofline_primitives": pprobe.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
