@@ -16,9 +16,24 @@ _ROW = 64      # bytes per tensor row of the device table (ptops_adamw_row_bytes
 class ClipAdamW(torch.optim.AdamW):
     def __init__(self, params, **kwargs):
         kwargs.pop("fused", None)
-        super().__init__(params, **kwargs)
-        self._plan = None
+        self._plan = None                      # before super().__init__: it calls add_param_group
         self._ring = 0
+        super().__init__(params, **kwargs)
+
+    def _sync_steps(self):
+        """Write the plan's step counts back into state[p]["step"] (torch's format) before anyone else reads them."""
+        if getattr(self, "_plan", None) is not None:
+            for p, n in zip(self._plan["params"], self._plan["steps"]):
+                self.state[p]["step"].fill_(float(n))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def step(self, closure=None):
+        self._sync_steps()
+        self._plan = None                              # the stock step advances the counters itself
+        return super().step(closure)
 
     # the plan caches the addresses of the moment tensors: anything that may replace them drops it
     def load_state_dict(self, state_dict):
@@ -26,6 +41,7 @@ class ClipAdamW(torch.optim.AdamW):
         return super().load_state_dict(state_dict)
 
     def add_param_group(self, param_group):
+        self._sync_steps()
         self._plan = None
         return super().add_param_group(param_group)
 
@@ -76,12 +92,16 @@ class ClipAdamW(torch.optim.AdamW):
         chunks[:, 1] = offset
         plan = {
             "key": tuple(id(p) for p in params), "params": params, "group_of": np.asarray(group_of), "rows": rows,
+            # step counts live here between checkpoints (335 CPU-tensor increments per step cost a millisecond of host
+            # time); `_sync_steps` writes them back into state[p]["step"] whenever somebody else may look
+            "steps": np.array([float(self.state[p]["step"]) for p in params], dtype=np.float64),
             "n_chunks": len(tensor_of),
             "chunks_dev": torch.from_numpy(chunks.view(np.uint8).reshape(-1)).to(dev),
             "rows_dev": torch.empty(n * _ROW, dtype=torch.uint8, device=dev),
             # pinned staging buffers in a ring: an async copy may still be reading the one of the previous steps
             "rows_host": [torch.empty(n * _ROW, dtype=torch.uint8).pin_memory() for _ in range(4)],
-            "rows_event": [None] * 4,
+            "rows_event": [torch.cuda.Event() for _ in range(4)],
+            "rows_used": [False] * 4,
             "partial": torch.empty(len(tensor_of), dtype=torch.float32, device=dev),
             "norm_coef": torch.empty(2, dtype=torch.float32, device=dev),
         }
@@ -96,20 +116,21 @@ class ClipAdamW(torch.optim.AdamW):
                 if p.grad is not None:
                     params.append(p)
                     group_of.append(gi)
-        if not self._supported(params):
-            return self._stock(max_norm)
         key = tuple(id(p) for p in params)
+        if self._plan is None or self._plan["key"] != key:              # the full eligibility check once per parameter set
+            if not self._supported(params):
+                self._sync_steps()
+                self._plan = None
+                return self._stock(max_norm)
         if (self._plan is None or self._plan["key"] != key
                 or any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(params[:4], self._plan["rows"][:4, 2]))):
+            self._sync_steps()                        # the old plan's counters go back into the state first
             self._plan = self._make_plan(params, group_of)
         plan = self._plan
         rows = plan["rows"]
         rows[:, 1] = [p.grad.data_ptr() for p in params]
-        steps = np.empty(len(params), dtype=np.float64)
-        for i, p in enumerate(params):
-            st = self.state[p]["step"]
-            st += 1
-            steps[i] = float(st)
+        plan["steps"] += 1.0
+        steps = plan["steps"]
         beta1, beta2 = self.param_groups[0]["betas"]
         eps = self.param_groups[0]["eps"]
         lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float32)[plan["group_of"]]
@@ -122,13 +143,12 @@ class ClipAdamW(torch.optim.AdamW):
         slot = self._ring
         self._ring = (self._ring + 1) % len(plan["rows_host"])
         host = plan["rows_host"][slot]
-        if plan["rows_event"][slot] is not None:
+        if plan["rows_used"][slot]:
             plan["rows_event"][slot].synchronize()      # the copy that read this buffer four steps ago (long done)
         host.numpy()[:] = rows.view(np.uint8).reshape(-1)
         plan["rows_dev"].copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        plan["rows_event"][slot] = ev
+        plan["rows_event"][slot].record()
+        plan["rows_used"][slot] = True
         _native.adamw_clip_step(plan["rows_dev"], len(params), plan["chunks_dev"], plan["n_chunks"],
                                 float(max_norm) if max_norm else 0.0, beta1, beta2, eps, plan["partial"], plan["norm_coef"])
         return plan["norm_coef"][0]

@@ -975,6 +975,7 @@ def test_clip_adamw_matches_torch(native):
             # a few ulp of the largest elements: the norm (hence the clip coefficient) is summed in another order
             tol = 8 * 2.0 ** -24 * float(a.detach().abs().max()) + 1e-7
             assert float((a.detach() - b.detach()).abs().max()) <= tol, (it, a.shape, float((a - b).abs().max()))
+    our.state_dict()                                             # writes the step counters back into the state
     for a, b in zip(ref_p, our_p):
         sa, sb = ref.state[a], our.state[b]
         assert set(sa) == set(sb) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == float(sb["step"])
