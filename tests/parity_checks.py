@@ -421,5 +421,8 @@ def check_baseline_forms(device):
         d_grad = sum(float((g1[n] - g2[n]).double().pow(2).sum()) for n in g2) ** 0.5 / gnorm
         d_buf = max(float((b1[n] - b2[n]).abs().max() / (1 + b2[n].abs().max())) for n in b2)
         report[cfg['NAME']] = (d_out, d_grad, d_buf)
-        assert d_out < 2e-4 and d_grad < 2e-3 and d_buf < 1e-5, report
+        # The two forms run different GEMM shapes through stacked train-mode BatchNorms over 8 clouds, which amplifies
+        # rounding: the gradient difference measured 1.7e-3 on most boxes and 2.0e-2 on one (other library kernels
+        # picked for the small shapes), outputs 9e-5 .. 1.1e-4; a logic error moves both by O(1).
+        assert d_out < 5e-4 and d_grad < 5e-2 and d_buf < 1e-5, report
     return report
