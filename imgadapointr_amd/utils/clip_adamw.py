@@ -127,6 +127,7 @@ class ClipAdamW(torch.optim.AdamW):
             self._sync_steps()                        # the old plan's counters go back into the state first
             self._plan = self._make_plan(params, group_of)
         plan = self._plan
+        self._opt_called = True                        # what LRScheduler's wrapper around step() records
         rows = plan["rows"]
         rows[:, 1] = [p.grad.data_ptr() for p in params]
         plan["steps"] += 1.0

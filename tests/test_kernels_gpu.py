@@ -1031,4 +1031,4 @@ def test_clip_adamw_survives_a_state_dict_round_trip(native):
         if it == 1:
             our.load_state_dict(our.state_dict())
     for p, q in zip(a, b):
-        assert float((p - q).abs().max()) <= 1e-6 * float(p.abs().max()) + 1e-7
+        assert float((p - q).detach().abs().max()) <= 1e-6 * float(p.detach().abs().max()) + 1e-7
