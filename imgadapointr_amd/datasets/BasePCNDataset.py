@@ -119,6 +119,22 @@ class PCN(BasePCNDataset):
 
 
 @DATASETS.register_module()
+class PCNv2(BasePCNDataset):
+    """PCN with partials up-sampled (tiled + random repeats) to 2048 instead of zero-padded
+    (datasets/PCNDataset.py:25-40 of the reference)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+
+    def _get_transforms(self, subset):
+        steps = [{'callback': 'UpSamplePoints', 'parameters': {'n_points': 2048}, 'objects': ['partial']}]
+        if subset == 'train':
+            steps.append({'callback': 'RandomMirrorPoints', 'objects': ['partial', 'gt']})
+        steps.append({'callback': 'ToTensor', 'objects': ['partial', 'gt']})
+        return data_transforms.Compose(steps)
+
+
+@DATASETS.register_module()
 class ImgPCN(BasePCNDataset):
     def __init__(self, config, num_imgs_per_obj=6):
         super().__init__(config, include_images=True, num_imgs_per_obj=num_imgs_per_obj)

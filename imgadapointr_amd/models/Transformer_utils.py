@@ -34,7 +34,7 @@ USE_MFMA_ATTENTION = True
 # 128 tokens up: 352 / 176 / 117 us at the bs = 32 decoder-self / cross / encoder shapes);
 # "fused": the single-pass f32-MFMA backward (5 GEMMs; 430 / 206 / 114 us);
 # False: PyTorch-ROCm's aten::_efficient_attention_backward, which consumes the same (out, logsumexp) pair
-USE_MFMA_ATTENTION_BWD = "split"
+USE_MFMA_ATTENTION_BWD = os.environ.get("PTOPS_ATTN_BWD", "split")       # A/B switch: split | fused
 _LN2 = 0.6931471805599453
 _bias_cache = {}
 _zero_cache = {}

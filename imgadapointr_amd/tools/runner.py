@@ -64,6 +64,7 @@ class TrainStep:
         self.ddp = model if isinstance(model, FlatDDP) else None
         self.params = [p for p in self.net.parameters() if p.requires_grad]
         self._num_iter = 0
+        self.before_update = None       # optional callable(): runs when the gradients of an update are complete
         self.zero_grad()
 
     def zero_grad(self):
@@ -72,8 +73,12 @@ class TrainStep:
         else:
             self.net.zero_grad(set_to_none=True)
 
-    def __call__(self, partial, gt, extra=(), epoch=0):
-        ret = self.model(partial, *extra)
+    def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None):
+        """`denoise_noise` ([B,64,3]) replaces the random jitter of the denoise seeds (fixture-driven parity runs)."""
+        if denoise_noise is None:
+            ret = self.model(partial, *extra)
+        else:
+            ret = self.model(partial, *extra, denoise_noise=denoise_noise)
         sparse_loss, dense_loss = self.net.get_loss(ret, gt, epoch)
         if self.ddp is not None:            # average only the backward that completes an update
             self.ddp.set_sync(self._num_iter + 1 == self.step_per_update)
@@ -86,6 +91,8 @@ class TrainStep:
             self._num_iter = 0
             if self.ddp is not None:
                 self.ddp.finalize()
+            if self.before_update is not None:
+                self.before_update()
             if hasattr(self.optimizer, "step_clipped") and FUSED_CLIP_ADAMW:
                 self.optimizer.step_clipped(self.clip)          # clip + AdamW of all parameters, three launches
             else:

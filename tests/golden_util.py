@@ -77,3 +77,88 @@ def demo_partial(pcd_path, n=2048):
 def synthetic_image(B, seed=0):
     """[B,3,224,224] float32 in [0,1): the value range torchvision's ToTensor produces."""
     return np.random.default_rng(seed).random((B, 3, 224, 224), dtype=np.float32)
+
+
+# ------------------------------------------------------------------ round 3: train-step cases and the demo-scan tree
+# One full train step at B = 2 of the three fused model families.  `ref_yaml` is the path inside the reference tree
+# (used by tests/golden/make_golden_round3.py only), `yaml` this repository's counterpart.
+TRAINSTEP_CASES = {
+    "img": dict(ref_yaml="cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml",
+                yaml="cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml", tag="imgadapointr",
+                takes_img=True, has_img=True, has_cls=False, frozen_segmentator=False, seed=411, epoch=7),
+    "seg": dict(ref_yaml="cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml",
+                yaml="cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml", tag="imgsegadapointr",
+                takes_img=True, has_img=True, has_cls=True, frozen_segmentator=True, seed=412, epoch=12),
+    "segenc": dict(ref_yaml="cfgs/SegImgPCN_models/SegEncAdaPoinTr.yaml",
+                   yaml="cfgs/SegImgPCN_models/SegEncAdaPoinTr.yaml", tag="segencadapointr",
+                   takes_img=True, has_img=False, has_cls=True, frozen_segmentator=True, seed=413, epoch=3),
+}
+
+
+def trainstep_state_dict(sd, case):
+    """Seeded weights of a train-step case.  On top of `seeded_state_dict`: the segmentator gets std 0.1 — with 0.02 its
+    activations are so small that its train-mode BatchNorms (batch statistics over B = 2) divide by sqrt(eps) and
+    amplify 1e-7 input differences to 0.1 at the output, which no implementation pair can reproduce — and the last
+    layer of coarse_pred gets std 0.08 so that the predicted coarse cloud is spread like a shape, not collapsed into a
+    cluster (degenerate neighbourhoods for the normals, near-tied query-ranking scores)."""
+    spec = TRAINSTEP_CASES[case]
+    out = seeded_state_dict(sd, spec["tag"])
+    wide = seeded_state_dict({k: v for k, v in sd.items() if ".segmentator." in k}, spec["tag"], std=0.1)
+    out.update(wide)
+    out.update(seeded_state_dict({k: v for k, v in sd.items() if k.endswith("coarse_pred.2.weight")}, spec["tag"], std=0.08))
+    return out
+
+
+def trainstep_inputs(case, B=2):
+    """(partial [B,2048,3], gt [B,16384,3], img [B,3,224,224] | None, cls_vec [B,16] | None) of a train-step case:
+    sphere-shell clouds with a zero-padded tail (SURVEY 8d's structured set), uniform images, one-hot classes 4 / 8."""
+    spec = TRAINSTEP_CASES[case]
+    partial, gt = synthetic_batch(B, 2048, 16384, seed=spec["seed"], structured=True)
+    img = synthetic_image(B, seed=spec["seed"] + 1000) if spec["has_img"] else None
+    cls = None
+    if spec["has_cls"]:
+        cls = np.zeros((B, 16), np.float32)
+        for b in range(B):
+            cls[b, (4, 8, 0, 15)[b % 4]] = 1.0
+    return partial, gt, img, cls
+
+
+def write_ascii_pcd(path, pts):
+    """[n,3] float32 -> ASCII .pcd with the header layout of the reference's demo scans; %.9g round-trips float32."""
+    import os
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    pts = np.asarray(pts, dtype=np.float32)
+    with open(path, "w") as fh:
+        fh.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\n"
+                 f"COUNT 1 1 1\nWIDTH {len(pts)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(pts)}\nDATA ascii\n")
+        for p in pts:
+            fh.write("%.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+
+
+def demo_tree_spec():
+    return {"taxonomies": ["02691156", "02933112", "02958343", "03001627", "03636649", "04256520", "04379243",
+                           "04530566"], "seed": 20263}
+
+
+def build_demo_tree(root, raws):
+    """A PCN-layout dataset tree under `root` from the 8 demo scans (`raws`: taxonomy -> [n,3] float32).
+    Per taxonomy: train model 't0' with 8 partial renderings (rendering i drops the last 37 i points of the scan),
+    val/test model 'v0' with the whole scan; complete clouds are seeded uniform 16384-point clouds, stored in the
+    ImgPCN layout `<subset>/complete/<tax>/<model>/PCN/<model>.pcd` (the 4-placeholder pattern the reference's
+    BasePCNDataset.py:70 formats; its own 3-placeholder cfgs/dataset_configs/PCN.yaml raises TypeError there)."""
+    import json
+    import os
+    spec = demo_tree_spec()
+    cats = []
+    for ti, tax in enumerate(spec["taxonomies"]):
+        raw = np.asarray(raws[tax], dtype=np.float32)
+        cats.append({"taxonomy_id": tax, "taxonomy_name": tax, "train": ["t0"], "val": ["v0"], "test": ["v0"]})
+        rng = np.random.default_rng(1000 + ti)
+        for subset, mid, nr in (("train", "t0", 8), ("val", "v0", 1), ("test", "v0", 1)):
+            gt = rng.random((16384, 3), dtype=np.float32) - 0.5
+            write_ascii_pcd(os.path.join(root, subset, "complete", tax, mid, "PCN", f"{mid}.pcd"), gt)
+            for i in range(nr):
+                write_ascii_pcd(os.path.join(root, subset, "partial", tax, mid, f"{i:02d}.pcd"),
+                                raw[:len(raw) - 37 * i])
+    with open(os.path.join(root, "PCN.json"), "w") as fh:
+        json.dump(cats, fh)

@@ -426,3 +426,136 @@ def check_baseline_forms(device):
         # picked for the small shapes), outputs 9e-5 .. 1.1e-4; a logic error moves both by O(1).
         assert d_out < 5e-4 and d_grad < 5e-2 and d_buf < 1e-5, report
     return report
+
+
+def build_trainstep_model(case, device):
+    """Model + config of a round-3 train-step case, seeded weights, segmentator frozen as tools/runner.py:55-66 does."""
+    from golden_util import TRAINSTEP_CASES, trainstep_state_dict
+    from imgadapointr_amd.models import build_model_from_cfg
+    from imgadapointr_amd.utils.config import cfg_from_yaml_file
+    spec = TRAINSTEP_CASES[case]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        cfg = cfg_from_yaml_file(spec["yaml"])
+    finally:
+        os.chdir(cwd)
+    model = build_model_from_cfg(cfg.model)
+    model.load_state_dict(trainstep_state_dict(model.state_dict(), case))
+    if spec["frozen_segmentator"]:
+        for p in model.base_model.segmentator.parameters():
+            p.requires_grad = False
+    return model.to(device), cfg, spec
+
+
+class _FixedDropout(torch.nn.Module):
+    """nn.Dropout(p) with the keep-mask given instead of drawn."""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.keep, self.p = keep, p
+
+    def forward(self, x):
+        return x * self.keep * (1.0 / (1.0 - self.p)) if self.training else x
+
+
+def check_trainstep(case, device):
+    """ONE full `TrainStep` (forward, get_loss, backward, clip + AdamW — the production step object of
+    tools/runner.py, fast paths as shipped) of a fused model family at B = 2 against the reference fixture
+    tests/golden/trainstep_<case>.npz: train outputs, both losses (CD-L1 x1000 within the north_star's 1e-3), the set
+    of parameters without gradient, total and sampled gradient norms, whole gradient vectors, parameters after the
+    update, and the frozen segmentator's running statistics (its BatchNorms stay in train mode, runner.py:115)."""
+    import json
+    from golden_util import trainstep_inputs
+    from imgadapointr_amd.tools import builder
+    from imgadapointr_amd.tools.runner import TrainStep
+    g = load(f"trainstep_{case}.npz")
+    with open(os.path.join(GOLD, f"trainstep_{case}.json")) as fh:
+        mt = json.load(fh)
+    model, cfg, spec = build_trainstep_model(case, device)
+    model.train()
+    named = dict(model.named_parameters())
+    assert sum(1 for p in named.values() if p.requires_grad) == mt["n_trainable"]
+    before = {n[len("after/"):]: named[n[len("after/"):]].detach().clone() for n in g.files if n.startswith("after/")}
+    step = TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
+    partial, gt, img, cls = trainstep_inputs(case)
+    extra = []
+    if img is not None:
+        extra.append(t(img, device))
+    elif spec["takes_img"]:
+        extra.append(None)
+    if cls is not None:
+        extra.append(t(cls, device))
+    # replay the reference's Dropout(0.4) masks of the (train-mode, frozen) GDANet, GDANet_ptseg.py:59-61
+    for i, name in enumerate(("dp1", "dp2")):
+        if f"dropout_mask_{i}" in g.files:
+            shape = tuple(int(x) for x in g[f"dropout_mask_{i}_shape"])
+            mask = np.unpackbits(g[f"dropout_mask_{i}"])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
+            setattr(model.base_model.segmentator, name, _FixedDropout(t(mask, device), 0.4))
+    grads, outs = {}, []
+    step.before_update = lambda: grads.update({n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None})
+    hook = model.register_forward_hook(lambda m, a, o: outs.append(o))
+    l_den, l_rec = step(t(partial, device), t(gt, device), tuple(extra), epoch=spec["epoch"],
+                        denoise_noise=t(g["train_noise"], device))
+    hook.remove()
+    ret = outs[0]
+    tol = 3e-4
+    d_out = (maxdiff(ret[1].detach().cpu().numpy(), g["denoised_coarse"]),
+             maxdiff(ret[2][:, :512].detach().cpu().numpy(), g["denoised_fine_head"]))
+    assert max(d_out) < tol, d_out
+    compare_ranked(ret[0].detach().cpu().numpy(), ret[3][:, :2048].detach().cpu().numpy(), g["pred_coarse"],
+                   g["pred_fine_head"], tol)
+    d_loss = (abs(l_den.item() - float(g["loss_denoised"])) * 1000, abs(l_rec.item() - float(g["loss_recon"])) * 1000)
+    assert max(d_loss) < 1e-3, d_loss
+    no_grad = sorted(n for n, p in named.items() if p.requires_grad and n not in grads)
+    assert no_grad == mt["no_grad_params"], (no_grad, mt["no_grad_params"])
+    assert not any(n in grads for n, p in named.items() if not p.requires_grad)
+    gsq = {n: float((v.double() ** 2).sum()) for n, v in grads.items()}
+    total, want_total = sum(gsq.values()), float(g["grad_sq_norm_total"])
+    # same resolution as the AdaPoinTr gradient check above: arg-max flips at rounding-level near-ties
+    assert abs(total - want_total) <= 5e-3 * want_total, (total, want_total)
+    d_norm = max(abs(gsq[n] - v) / max(v, 1e-12) for n, v in mt["grad_sq_norm_sample"].items() if v > 1e-9 * want_total)
+    assert d_norm < 3e-2, d_norm
+    d_vec = {}
+    for key in g.files:
+        if key.startswith("grad/"):
+            n = key[len("grad/"):]
+            want = g[key].astype(np.float64)
+            got = grads[n].double().cpu().numpy()
+            if np.linalg.norm(want) < 1e-4 * np.sqrt(want_total):
+                # e.g. a k_map bias: softmax is invariant to a constant added to every key's logit, so this gradient is
+                # zero in exact arithmetic and pure rounding noise in both implementations; only its size is checked
+                assert np.linalg.norm(got) < 1e-3 * np.sqrt(want_total), n
+                continue
+            d_vec[n] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    assert len(d_vec) >= 12 and max(d_vec.values()) < 3e-2, d_vec
+    assert abs(float(np.sqrt(total)) - float(g["grad_norm_before_clip"])) < 3e-3 * float(g["grad_norm_before_clip"])
+    # after the update: AdamW's first step moves every element by ~lr * sign(g) (lr 1e-4), so an element whose gradient
+    # is at rounding level may land 2e-4 away; everything else must agree to a small fraction of one step
+    lr = float(cfg.optimizer.kwargs.lr)
+    moved, far, n_el = 0.0, 0, 0
+    for n, b in before.items():
+        want = g["after/" + n]
+        got = named[n].detach().reshape(-1)[:4096].cpu().numpy()
+        was = b.reshape(-1)[:4096].cpu().numpy()
+        if np.abs(want - was).max() < 0.2 * lr:       # a k_map bias again: gradient at rounding level, below Adam's eps
+            assert np.abs(got - was).max() < 1.1 * lr, n
+            continue
+        diff = np.abs(got - want)
+        far += int((diff > 0.05 * lr).sum())
+        n_el += diff.size
+        assert diff.max() <= 2.2 * lr, (n, diff.max())
+        moved = max(moved, float(np.abs(got - was).max()))
+    # a gradient vector that agrees to 1-2 % (arg-max flips, above) has about that share of elements near zero whose
+    # sign, and with it the whole first step, may differ
+    assert far <= 0.06 * n_el, (far, n_el)
+    assert 0.5 * lr < moved < 1.5 * lr, moved
+    d_rm = None
+    if "seg_first_running_mean" in g.files:
+        bn = next(m for m in model.base_model.segmentator.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        d_rm = maxdiff(bn.running_mean.cpu().numpy(), g["seg_first_running_mean"])
+        assert d_rm < 1e-5, d_rm
+        assert all(p.grad is None for p in model.base_model.segmentator.parameters())
+    return dict(out=d_out, loss_x1000=d_loss, grad_total_rel=abs(total - want_total) / want_total, grad_sample_rel=d_norm,
+                grad_vec_rel=max(d_vec.values()), after_far_frac=far / n_el, seg_running_mean=d_rm)

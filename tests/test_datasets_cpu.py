@@ -174,3 +174,50 @@ def test_pcd_reader_binary_compressed(tmp_path):
         fh.write(np.asarray([len(comp), len(raw)], dtype="<u4").tobytes())
         fh.write(comp)
     assert np.array_equal(IO.get(str(tmp_path / "c.pcd")).astype(np.float32), pts)
+
+
+def test_readers_and_transforms_match_the_reference_on_the_demo_scans(tmp_path):
+    """tests/golden/demo_data.npz: the reference's PCN / PCNv2 dataset classes (reader -> RandomSamplePoints /
+    UpSamplePoints -> RandomMirrorPoints -> ToTensor) run over a tree made of the 8 real scans of its demo/samples,
+    seeded RNGs (generator: tests/golden/make_golden_round3.py).  The same tree is rebuilt here from the fixture's
+    raw clouds; items must agree bit for bit: file parsing, RNG draw order, padding, mirroring."""
+    import hashlib
+    import random
+    from golden_util import build_demo_tree, demo_tree_spec
+    from imgadapointr_amd.datasets import build_dataset_from_cfg
+    from imgadapointr_amd.utils.config import EasyDict
+    from imgadapointr_amd.utils.io_module import IO
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_data.npz"))
+    spec = demo_tree_spec()
+    raws = {t: g[f"raw/{t}"] for t in spec["taxonomies"]}
+    assert sorted(len(r) for r in raws.values())[0] >= 700          # real scans: 708 .. 1850 points
+    root = str(tmp_path)
+    build_demo_tree(root, raws)
+    for t in spec["taxonomies"]:                                      # the reader returns the scan's float32 values
+        got = IO.get(os.path.join(root, "val", "partial", t, "v0", "00.pcd"))
+        assert got.dtype == np.float64 and np.array_equal(got.astype(np.float32), raws[t])
+    n_items = 0
+    for name in ("PCN", "PCNv2"):
+        for subset in ("train", "val"):
+            base = EasyDict(NAME=name, CATEGORY_FILE_PATH=os.path.join(root, "PCN.json"), N_POINTS=16384,
+                            N_RENDERINGS=8, CARS=False, PARTIAL_POINTS_PATH=root + "/%s/partial/%s/%s/%02d.pcd",
+                            COMPLETE_POINTS_PATH=root + "/%s/complete/%s/%s/PCN/%s.pcd")
+            ds = build_dataset_from_cfg(base, EasyDict(subset=subset))
+            random.seed(spec["seed"])
+            np.random.seed(spec["seed"])
+            ids = [str(x) for x in g[f"{name}/{subset}/ids"]]
+            assert len(ds) == len(ids) == 8
+            for i in range(len(ds)):
+                tax, mid, (partial, gt) = ds[i]
+                assert f"{tax}/{mid}" == ids[i]
+                want = g[f"{name}/{subset}/{i}/partial"]
+                assert partial.dtype == torch.float32 and tuple(partial.shape) == want.shape == (2048, 3)
+                assert np.array_equal(partial.numpy(), want), (name, subset, i)
+                if name == "PCN":                                    # zero padding of the short scans survives
+                    assert int((np.abs(want).sum(-1) == 0).sum()) == max(0, 2048 - (len(raws[tax]) - 0))  \
+                        or subset == "train"
+                assert np.array_equal(gt[:64].numpy(), g[f"{name}/{subset}/{i}/gt_head"])
+                sha = np.frombuffer(hashlib.sha1(np.ascontiguousarray(gt.numpy()).tobytes()).digest(), dtype=np.uint8)
+                assert np.array_equal(sha, g[f"{name}/{subset}/{i}/gt_sha1"])
+                n_items += 1
+    assert n_items == 32

@@ -122,3 +122,9 @@ def test_analytic_normals_eigenvector_matches_eigh():
     out = N.smallest_eigenvector_sym3(deg)                    # no defined normal: a unit vector of the eigen-plane
     assert torch.isfinite(out).all() and ((out.norm(dim=-1) - 1).abs() < 1e-12).all()
     assert abs(float(out[2, 0])) < 1e-12                      # orthogonal to the eigenvector of the largest eigenvalue
+
+
+@pytest.mark.parametrize("case", ["img", "seg", "segenc"])
+def test_full_train_step_of_the_fused_families_matches_reference(case):
+    """BASELINE configs[2] / [4] and SegEncAdaPoinTr: one production TrainStep at B = 2 vs the reference fixture."""
+    print(pc.check_trainstep(case, "cpu"))

@@ -65,3 +65,10 @@ def test_kernels_run_on_the_current_stream():
     s.synchronize()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["img", "seg", "segenc"])
+def test_full_train_step_of_the_fused_families_matches_reference(case):
+    """BASELINE configs[2] / [4] and SegEncAdaPoinTr: one production TrainStep (split-bf16 GEMMs and attention, deferred
+    folds, fused clip + AdamW) at B = 2 on the HIP path vs the reference fixture."""
+    print(pc.check_trainstep(case, "cuda"))
