@@ -45,11 +45,23 @@ FLOP_PER_PAIR = 8                 # 3 sub + 3 mul + 2 add per squared distance (
 N_PARTIAL, N_GT, BATCH = 2048, 16384, 32
 
 
-def load_cfg():
+# --model: the three model families of BASELINE.json's configs.  The headline metric (configs[1] / [3]) is "adapointr";
+# "img" = configs[2] (image cross-attention fusion, bs 16), "seg" = configs[4] (image + segmentation branch, bs 16).
+MODELS = {
+    "adapointr": dict(yaml="cfgs/PCN_models/AdaPoinTr.yaml", batch=32, img=False, cls=False, config="configs[1]",
+                      name="AdaPoinTr"),
+    "img": dict(yaml="cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml", batch=16, img=True, cls=False,
+                config="configs[2]", name="ImgResNetEncAdaPoinTrVariableLoss (ImgAdaPoinTr)"),
+    "seg": dict(yaml="cfgs/SegImgPCN_models/ImgEncSegDecAdaPoinTrVariableLoss.yaml", batch=16, img=True, cls=True,
+                config="configs[4]", name="ImgEncSegDecAdaPoinTrVariableLoss (ImgEncSegDecAPTr)"),
+}
+
+
+def load_cfg(which="adapointr"):
     cwd = os.getcwd()
     os.chdir(ROOT)
     try:
-        return cfg_from_yaml_file("cfgs/PCN_models/AdaPoinTr.yaml")
+        return cfg_from_yaml_file(MODELS[which]["yaml"])
     finally:
         os.chdir(cwd)
 
@@ -145,8 +157,8 @@ class AttentionProbe:
     def _on_bf16_pipe(q, k, backward, fused):
         Nq, Nk = q.size(2), k.size(2)
         if backward:
-            return (not fused) and Nq >= 128 and Nk >= 128 and "PTOPS_ATTN_BWD_F32" not in os.environ
-        return Nq >= 128 and "PTOPS_ATTN_FWD_F32" not in os.environ
+            return (not fused) and Nq >= 128 and Nk >= 128 and not _native.get_option("PTOPS_ATTN_BWD_F32")
+        return Nq >= 128 and not _native.get_option("PTOPS_ATTN_FWD_F32")
 
     def forward(self, q, k, v, split_q, limit_k, scale):
         if not self.enabled:
@@ -303,7 +315,7 @@ class PrimitiveProbe:
         return out
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, spec, budget_s=20.0):
     """The same train step on the host cores through the CPU oracle, B=2 (BASELINE configs[0])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import ref as oracle
@@ -321,12 +333,19 @@ def cpu_baseline(cfg, budget_s=20.0):
     try:
         torch.manual_seed(0)
         model = build_model_from_cfg(cfg.model)
+        if spec["cls"]:
+            for p in model.base_model.segmentator.parameters():
+                p.requires_grad = False
         model.train()
         opt = builder.build_optimizer(model, cfg)
         step = TrainStep(model, opt)
         B = 2
         partial = torch.rand(B, N_PARTIAL, 3) - 0.5
         gt = torch.rand(B, N_GT, 3) - 0.5
+        extra = ((torch.rand(B, 3, 224, 224),) if spec["img"] else ()) + \
+                ((torch.eye(16)[:B].contiguous(),) if spec["cls"] else ())
+        _step = step
+        step = lambda p, g: _step(p, g, extra)        # noqa: E731
         tw = time.time()
         step(partial, gt)  # warm-up
         tw = time.time() - tw
@@ -352,7 +371,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="clouds per GPU (the metric is quoted at 32)")
+    ap.add_argument("--model", choices=sorted(MODELS), default="adapointr",
+                    help="adapointr = BASELINE configs[1] (the headline metric); img = configs[2]; seg = configs[4]")
+    ap.add_argument("--views", type=int, default=1,
+                    help="img / seg only: renders per object in the batch ([B,V,3,224,224]; the README's 6 / 12-view "
+                         "protocol).  1 = the reference's train step (one render per sample).  With V > 1 a step "
+                         "trains on B objects x V views = B*V samples; the point branch runs once per object")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clouds (objects) per GPU; default 32 for adapointr, 16 for img / seg (BASELINE.json configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the GEMM kernel choice to the library default")
     args = ap.parse_args()
@@ -385,9 +411,17 @@ def main():
     _native.load()
     gemm = "library default" if args.no_gemm_tuning else enable_tuned_gemm()
 
-    cfg = load_cfg()
+    spec = MODELS[args.model]
+    if args.batch is None:
+        args.batch = spec["batch"]
+    if args.views != 1 and not spec["img"]:
+        raise SystemExit("--views needs a model with an image branch (--model img | seg)")
+    cfg = load_cfg(args.model)
     torch.manual_seed(0)                     # identical weights on every rank
     model = build_model_from_cfg(cfg.model).to(device)
+    if spec["cls"]:                          # the runner freezes the segmentator (tools/runner.py:55-66)
+        for p in model.base_model.segmentator.parameters():
+            p.requires_grad = False
     model.train()
     # PTOPS_BENCH_FORCE_DDP=1 wraps the model at N=1 too (hooks + bucket packing, no collective): a way to see
     # the data-parallel bookkeeping overhead on a one-GPU box.  Never the default.
@@ -399,6 +433,16 @@ def main():
     B = args.batch
     partial = (torch.rand(B, N_PARTIAL, 3) - 0.5).to(device)
     gt = (torch.rand(B, N_GT, 3) - 0.5).to(device)
+    extra = []
+    if spec["img"]:
+        shape = (B, 3, 224, 224) if args.views == 1 else (B, args.views, 3, 224, 224)
+        extra.append(torch.rand(*shape).to(device))
+    if spec["cls"]:
+        cls_vec = torch.zeros(B, 16)
+        cls_vec[torch.arange(B), torch.tensor([0, 4, 8, 15])[torch.arange(B) % 4]] = 1.0    # SegImgPCNDataset.py:5-12
+        extra.append(cls_vec.to(device))
+    extra = tuple(extra)
+    samples = B * args.views
 
     probe = ChamferProbe(N_GT, N_GT)
     _native.chamfer_forward = probe
@@ -419,7 +463,7 @@ def main():
 
     note("model built; warm-up")
     for i in range(args.warmup):
-        step(partial, gt)
+        step(partial, gt, extra)
         if i == 0:
             torch.cuda.synchronize()
             note("first step done")
@@ -429,7 +473,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
-        last = step(partial, gt)
+        last = step(partial, gt, extra)
         aprobe.enabled = pprobe.enabled = gprobe.enabled = False   # ~270 timing events per step cost ~1 ms: only the first timed step carries them
     barrier()
     dt = time.perf_counter() - t0
@@ -448,14 +492,21 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "clouds/sec (train step, bs=32/GPU), AdaPoinTr PCN 2048->16384",
-            "value": round(world * B * args.steps / dt, 3), "unit": "clouds/s",
+            "metric": (f"clouds/sec (train step, bs={B}/GPU), AdaPoinTr PCN 2048->16384" if args.model == "adapointr" else
+                       f"clouds/sec (train step, bs={B}/GPU" + (f" x {args.views} views" if args.views > 1 else "") +
+                       f"), {spec['name']} PCN 2048->16384"),
+            "value": round(world * samples * args.steps / dt, 3), "unit": "clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo)" if rehearsal else ""),
-            "config": {"workload": "AdaPoinTr cfgs/PCN_models/AdaPoinTr.yaml, PCN 2048->16384, "
-                                   f"bs={B}/GPU, full train step (BASELINE configs[1])",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "gemm_selection": gemm,
+            "config": {"workload": f"{spec['name']} {spec['yaml']}, PCN 2048->16384, bs={B}/GPU"
+                                   + (", one 3x224x224 render per sample" if spec["img"] and args.views == 1 else "")
+                                   + (f", {args.views} renders per object folded into the batch ([{B},{args.views},3,224,224] -> "
+                                      f"{samples} samples per step; grouper + point encoder once per object; a cloud = one "
+                                      "(object, view) sample)" if args.views > 1 else "")
+                                   + (", 16-class one-hot + frozen GDANet segmentator" if spec["cls"] else "")
+                                   + f", full train step (BASELINE {spec['config']})",
+                       "global_batch": world * B, "samples_per_step": world * samples, "parallelism": f"dp{world}", "gemm_selection": gemm,
                        "gemm_arithmetic": ("fp32 in / fp32 out everywhere; Linear forward, input-gradient and the larger weight-gradient "
                                            "GEMMs with >= 16384 rows run on libptops' split-bf16 kernels (three bf16 pieces per operand, six exact piece "
                                            "products, fp32 accumulation: error vs float64 <= the fp32 MFMA library kernels, "
@@ -470,7 +521,7 @@ def main():
             "roofline_primitives": pprobe.summary(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, spec)
         print(json.dumps(out), flush=True)
     if world > 1 or single_rank_rccl:
         dist.barrier()

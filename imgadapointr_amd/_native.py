@@ -62,7 +62,9 @@ def _declare(lib):
         "ptops_adamw_chunk_elements": (c_int, []),
         "ptops_adamw_clip_step": (c_int, [P, c_int, P, c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           P, P, P]),
-        "ptops_fold_defer": (c_int, [c_int]),
+        "ptops_fold_defer": (c_int, [P, c_int]),
+        "ptops_set_option": (c_int, [ctypes.c_char_p, c_int]),
+        "ptops_get_option": (c_int, [ctypes.c_char_p]),
         "ptops_fold_flush": (c_int, [P]),
         "ptops_max_tokens_forward": (c_int, [P, c_int, c_int, c_int, P, P, P]),
         "ptops_gemm_f32_split3": (c_int, [P, ctypes.c_longlong, c_int, P, ctypes.c_longlong, c_int, P, ctypes.c_longlong,
@@ -104,7 +106,7 @@ EXPORTS = (
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
-    "ptops_fold_defer", "ptops_fold_flush", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
+    "ptops_fold_defer", "ptops_fold_flush", "ptops_set_option", "ptops_get_option", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
     "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad", "ptops_gemm_f32_split3_gelu",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
@@ -597,49 +599,76 @@ _colsum_ws = {}
 
 # ---- deferred folds (include/ptops.h): the tiny final launches of the column-sum producers, batched -----------------
 _fold_deferred = False
+_fold_stream = None           # (device, raw stream handle) deferral is switched on for
 _fold_keepalive = []          # workspaces / outputs of queued folds: alive until the flush
 _fold_seen = set()            # parameters that already got a (possibly still queued) gradient in this backward pass
+_fold_plain = set()           # parameters that ALSO take part in a forward through a plain (aten) path: never adopted unread
+FOLD_POISON = os.environ.get("PTOPS_FOLD_POISON", "0") == "1"   # debug: queued outputs are NaN until the flush
 
 
 class deferred_folds:
     """Context manager for a backward pass whose bias / LayerNorm-weight gradients are read only afterwards (or after a
     `fold_flush()`, as FlatDDP does before it packs a bucket): the ~115 fold launches become a few batched ones.
-    Do NOT use it when `.grad` already holds a value that backward accumulates into (gradient accumulation)."""
+    Deferral is switched on for the CURRENT stream of `device` only (the C side keeps one queue per stream).
+
+    What makes it safe, and what is checked:
+      * a queued gradient must be adopted by autograd unread, i.e. `.grad` of every parameter must be None when the
+        backward starts: pass `params` and the context refuses to defer (plain immediate folds) if any holds a value;
+      * a parameter that gets a second gradient in the same pass - from a deferring producer (`fold_returning` sees the
+        key twice) or from a plain aten path (`fold_mark_plain` at forward time) - is flushed before it is handed over;
+      * `PTOPS_FOLD_POISON=1` fills every queued output with NaN until the flush: a premature read cannot stay silent."""
+
+    def __init__(self, params=None, device=None):
+        self.params = params
+        self.device = device
 
     def __enter__(self):
-        global _fold_deferred
+        global _fold_deferred, _fold_stream
         _fold_seen.clear()
-        if _test_backend is None:
-            load().ptops_fold_defer(1)
-            _fold_deferred = True
+        if _test_backend is None and (self.params is None or all(p.grad is None for p in self.params)):
+            dev = self.device
+            if dev is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            handle = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            load().ptops_fold_defer(handle, 2 if FOLD_POISON else 1)
+            _fold_deferred, _fold_stream = True, (dev, handle)
         return self
 
     def __exit__(self, *exc):
-        global _fold_deferred
+        global _fold_deferred, _fold_stream
         if _fold_deferred:
             _fold_deferred = False
-            load().ptops_fold_defer(0)
+            load().ptops_fold_defer(_fold_stream[1], 0)
             fold_flush()
+            _fold_stream = None
+        _fold_plain.clear()
         return False
+
+
+def fold_mark_plain(*keys):
+    """Forward-time note: the parameters `keys` (data_ptr) are used through a plain autograd path in this forward, so
+    their gradient may be accumulated by the engine; a deferring producer must not hand them a queued buffer."""
+    _fold_plain.update(k for k in keys if k is not None)
 
 
 def fold_returning(key):
     """Call where a backward node hands a possibly queued gradient of parameter `key` (any hashable, e.g. its
     data_ptr) to autograd.  The first gradient of a parameter is adopted unread; a SECOND one in the same backward
-    pass (a module applied twice) is added to the first by the engine at once, so everything queued is folded first."""
+    pass (a module applied twice, or a plain aten path on the same parameter) is added to the first by the engine at
+    once, so everything queued is folded first."""
     if _fold_deferred:
-        if key in _fold_seen:
+        if key in _fold_seen or key in _fold_plain:
             fold_flush()
-        else:
-            _fold_seen.add(key)
+        _fold_seen.add(key)
 
 
 def fold_flush():
-    """Runs the queued folds on the current stream (no-op when nothing is queued)."""
+    """Runs the queued folds on the stream they were queued on (no-op when nothing is queued)."""
     if _fold_keepalive:
         dev = _fold_keepalive[0].device
         with torch.cuda.device(dev):
-            _call("ptops_fold_flush", ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _call("ptops_fold_flush", handle)
         _fold_keepalive.clear()
         for slot in _fold_arena.values():               # stream order: the next producers write after this flush
             slot[1] = 0
@@ -992,3 +1021,15 @@ def edge_scatter(dense, sel, idx, nsel, Nk):
         _call("ptops_edge_scatter", _ptr(dense), _ptr(sel), _ptr(idx), _ptr(nsel), B, C, int(Nk), Nq, k, _ptr(T),
               _stream(dense))
     return T
+
+
+def set_option(name, value):
+    """A/B switch of the library (include/ptops.h, ptops_set_option); -> the previous value."""
+    old = load().ptops_set_option(name.encode(), int(value))
+    if old < 0:
+        raise PtopsError(f"unknown libptops option {name!r}")
+    return old
+
+
+def get_option(name):
+    return load().ptops_get_option(name.encode())

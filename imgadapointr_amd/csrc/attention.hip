@@ -1367,13 +1367,13 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   // 108/89/90/77 us (576x256), 58/47/58/43 us (256x256).
   // >= 4 query tiles: the bf16-matrix-pipe kernel (fp32-accurate three-piece split, attn_fwd_split3_kernel);
   // PTOPS_ATTN_FWD_F32=1 keeps the f32-MFMA kernel
-  if (tiles >= 4 && getenv("PTOPS_ATTN_FWD_F32") == nullptr) {
+  if (tiles >= 4 && !ptops::option("PTOPS_ATTN_FWD_F32")) {
     hipLaunchKernelGGL(attn_fwd_split3_kernel, dim3(ptops::ceil_div(tiles, 4), B * H), dim3(256), 0, stream, a);
     return ptops::check_launch("attn_fwd_split3_kernel");
   }
   int W = tiles < 4 ? tiles : 4;
-  if (const char* force = getenv("PTOPS_ATTN_FWD_WAVES")) {                 // benchmarking knob
-    if (force[0] >= '1' && force[0] <= '4') W = force[0] - '0';
+  if (const int force = ptops::option("PTOPS_ATTN_FWD_WAVES")) {            // benchmarking knob
+    if (force >= 1 && force <= 4) W = force;
   }
   dim3 grid(ptops::ceil_div(tiles, W), B * H);
   switch (W) {
@@ -1420,14 +1420,13 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   // >= 4 tiles on both sides: the bf16-matrix-pipe pair (fp32-accurate three-piece split); PTOPS_ATTN_BWD_F32=1 keeps
   // the f32-MFMA kernels for A/B runs
-  static const bool f32_only = getenv("PTOPS_ATTN_BWD_F32") != nullptr;
+  const bool f32_only = ptops::option("PTOPS_ATTN_BWD_F32") != 0;
   if (!f32_only && Nq >= 128 && Nk >= 128) {
     hipLaunchKernelGGL(attn_bwd_dq_split3_kernel, dim3(ptops::ceil_div(Nq / 32, 4), B * H), dim3(256), 0, stream, a);
     int rc = ptops::check_launch("attn_bwd_dq_split3_kernel");
     if (rc != PTOPS_OK) return rc;
     const int ktiles = Nk / 32;
-    const char* dkv_env = getenv("PTOPS_ATTN_DKV_WAVES");
-    const int dkv_waves = dkv_env ? atoi(dkv_env) : 8;
+    const int dkv_waves = ptops::option("PTOPS_ATTN_DKV_WAVES") == 4 ? 4 : 8;
     if (dkv_waves == 4)
       hipLaunchKernelGGL(attn_bwd_dkv_split3_kernel<4>, dim3(ptops::ceil_div(ktiles, 4), B * H), dim3(256), 0, stream, a);
     else
@@ -1480,8 +1479,8 @@ static int fused_query_splits(long long BH, int Nq, int Nk, int limit_k) {
   const long long slots = (long long)ptops::kNumCU * (fw == 8 ? 1 : 2);
   const long long blocks = BH * ptops::ceil_div(limit_k < Nk ? limit_k : Nk, fw * 32);   // the others see few queries
   if (Nq / kTK < 8) return 1;
-  if (const char* force = getenv("PTOPS_ATTN_QSPLIT")) {
-    if (force[0] == '1' || force[0] == '2') return force[0] - '0';
+  if (const int force = ptops::option("PTOPS_ATTN_QSPLIT")) {
+    if (force == 1 || force == 2) return force;
   }
   if (Nq / kTK < 16) return 1;
   if (2 * blocks <= slots) return 2;

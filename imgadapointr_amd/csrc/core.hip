@@ -1,6 +1,10 @@
 // libptops: ABI version, the thread-local error message and the fill kernel used instead of hipMemsetAsync.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "ptops_common.h"
 
@@ -44,6 +48,45 @@ int fill_async(void* ptr, int value, size_t bytes, hipStream_t stream) {
   return check_launch("fill_bytes_kernel");
 }
 }  // namespace ptops
+
+// ---- A/B switches: every switch is read from the environment ONCE (first use) and can be changed afterwards only
+// through ptops_set_option, so that a label printed by a benchmark and the kernel that ran cannot disagree.
+namespace ptops {
+namespace {
+struct Option {
+  const char* name;
+  int value;
+};
+Option g_options[] = {{"PTOPS_ATTN_FWD_F32", 0},  {"PTOPS_ATTN_BWD_F32", 0}, {"PTOPS_ATTN_FWD_WAVES", 0},
+                      {"PTOPS_ATTN_DKV_WAVES", 0}, {"PTOPS_ATTN_QSPLIT", 0}, {"PTOPS_GEMM_PINGPONG", 1}};
+std::once_flag g_options_once;
+void read_options() {
+  for (Option& o : g_options)
+    if (const char* v = getenv(o.name)) o.value = (v[0] >= '0' && v[0] <= '9') ? atoi(v) : 1;
+}
+}  // namespace
+int option(const char* name) {
+  std::call_once(g_options_once, read_options);
+  for (const Option& o : g_options)
+    if (strcmp(o.name, name) == 0) return o.value;
+  return 0;
+}
+}  // namespace ptops
+
+// Sets an A/B switch (names = the environment variables that initialise them).  Returns the previous value or -1 for an
+// unknown name.  Not a tuning interface: the defaults are what is measured and tested.
+PTOPS_API int ptops_set_option(const char* name, int value) {
+  std::call_once(ptops::g_options_once, ptops::read_options);
+  for (ptops::Option& o : ptops::g_options)
+    if (name && strcmp(o.name, name) == 0) {
+      const int old = o.value;
+      o.value = value;
+      return old;
+    }
+  ptops::set_error("set_option: unknown option");
+  return -1;
+}
+PTOPS_API int ptops_get_option(const char* name) { return name ? ptops::option(name) : 0; }
 
 PTOPS_API int ptops_abi_version(void) { return 1; }
 PTOPS_API const char* ptops_last_error(void) { return ptops::g_err; }

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void adamw_sumsq_kernel(const TensorRow* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (max_norm <= 0: no clipping)
+// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)), NaN if the norm is NaN
+// (max_norm <= 0: no clipping)
 __global__ __launch_bounds__(1024) void adamw_norm_kernel(const float* __restrict__ partial, int n, float max_norm,
                                                           float* __restrict__ out) {
   __shared__ float red[16];
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(1024) void adamw_norm_kernel(const float* __restric
     for (int w = 0; w < 16; ++w) s += red[w];
     const float norm = sqrtf(s);
     out[0] = norm;
-    out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    // torch.clamp(max_norm / (norm + 1e-6), max=1.0): a NaN norm gives a NaN coefficient that poisons every gradient
+    // and parameter, exactly as clip_grad_norm_ + step() of the reference does (fminf would hide it behind a 1)
+    const float c = max_norm / (norm + 1e-6f);
+    out[1] = max_norm > 0.f ? (c < 1.0f ? c : (c != c ? c : 1.0f)) : 1.0f;
   }
 }
 

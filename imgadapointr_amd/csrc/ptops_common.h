@@ -28,6 +28,9 @@ __host__ __device__ inline long long ceil_div_ll(long long a, long long b) { ret
 // memset(ptr, value, bytes) as a kernel on `stream` (never a hipMemsetAsync: see core.hip)
 int fill_async(void* ptr, int value, size_t bytes, hipStream_t stream);
 
+// core.hip: A/B switch `name` (an environment variable read once at first use; ptops_set_option changes it)
+int option(const char* name);
+
 constexpr int kNumCU = 256;   // MI355X
 constexpr int kWave = 64;
 

@@ -10,6 +10,8 @@
 #include <mutex>
 #include <vector>
 
+#include <unordered_map>
+
 #include "ptops_common.h"
 
 namespace {
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(16 * RY) void colsum_final_kernel(const float* __re
 }  // namespace
 
 // ---- deferred folds: the ~115 tiny fold launches of a backward pass (bias, LayerNorm and GELU-bias gradients) as a few
-// batched ones.  One GPU per process; the queue is process-wide because autograd runs backward nodes on its own thread.
+// batched ones.  The queues are keyed by stream (autograd runs backward nodes on its own thread, but on the stream of
+// the forward), guarded by one mutex.
 namespace {
 
 constexpr int kMaxBatch = 96;
@@ -163,9 +166,22 @@ struct PendingFold {
   float* out;
   int S, N;
 };
+// One queue per stream: deferral is switched on for ONE stream (the stream backward runs on) and only folds that are
+// launched on that stream are queued; a fold on any other stream runs at once.  The queues are the only state the
+// library keeps between calls (include/ptops.h); they hold no device memory.
+struct FoldQueue {
+  bool defer = false;
+  bool poison = false;
+  std::vector<PendingFold> pending;
+};
 std::mutex g_fold_mutex;
-std::vector<PendingFold> g_pending;
-bool g_defer = false;
+std::unordered_map<hipStream_t, FoldQueue> g_queues;
+
+// debug aid (ptops_fold_defer(stream, 2)): the output of a queued fold is filled with NaN until the flush writes it
+__global__ __launch_bounds__(256) void fold_poison_kernel(float* out, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = __builtin_nanf("");
+}
 
 template <int RY>
 int launch_batches(const std::vector<PendingFold>& items, hipStream_t stream) {
@@ -191,9 +207,21 @@ int launch_batches(const std::vector<PendingFold>& items, hipStream_t stream) {
 
 int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipStream_t stream, bool deferrable) {
   if (deferrable) {
-    std::lock_guard<std::mutex> lock(g_fold_mutex);
-    if (g_defer) {
-      g_pending.push_back({partial, out, S, N});
+    bool queued = false, poison = false;
+    {
+      std::lock_guard<std::mutex> lock(g_fold_mutex);
+      auto it = g_queues.find(stream);
+      if (it != g_queues.end() && it->second.defer) {
+        it->second.pending.push_back({partial, out, S, N});
+        queued = true;
+        poison = it->second.poison;
+      }
+    }
+    if (queued) {
+      if (poison) {
+        hipLaunchKernelGGL(fold_poison_kernel, dim3(ptops::ceil_div(N, 256)), dim3(256), 0, stream, out, N);
+        return ptops::check_launch("fold_poison_kernel");
+      }
       return PTOPS_OK;
     }
   }
@@ -204,23 +232,31 @@ int ptops_reduce::fold_rows(const float* partial, int S, int N, float* out, hipS
   return ptops::check_launch("colsum_final_kernel");
 }
 
-// on != 0: deferrable folds (ptops_colsum, ptops_layer_norm_backward, ptops_gelu_backward_colsum) are queued until
-// ptops_fold_flush; the caller keeps their workspaces and outputs alive and unread until then.  Returns the number of
-// folds still queued (switching off does not flush).
-PTOPS_API int ptops_fold_defer(int on) {
+// mode != 0: deferrable folds (ptops_colsum, ptops_layer_norm_backward, ptops_gelu_backward_colsum) launched on `stream`
+// are queued until ptops_fold_flush(stream); the caller keeps their workspaces and outputs alive and unread until then.
+// mode 2 additionally fills every queued output with NaN (debug: a premature read shows).  Returns the number of folds
+// still queued on that stream (switching off does not flush).
+PTOPS_API int ptops_fold_defer(void* stream_, int mode) {
   std::lock_guard<std::mutex> lock(g_fold_mutex);
-  g_defer = on != 0;
-  return (int)g_pending.size();
+  FoldQueue& q = g_queues[(hipStream_t)stream_];
+  q.defer = mode != 0;
+  q.poison = mode == 2;
+  const int n = (int)q.pending.size();
+  if (!q.defer && q.pending.empty()) g_queues.erase((hipStream_t)stream_);
+  return n;
 }
 
-// Launches every queued fold on `stream` (the stream their producers ran on): one launch per 96 folds and size class.
+// Launches every fold queued on `stream`: one launch per 96 folds and size class.
 PTOPS_API int ptops_fold_flush(void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   std::vector<PendingFold> small, large;
   {
     std::lock_guard<std::mutex> lock(g_fold_mutex);
-    for (const PendingFold& f : g_pending) (f.S > 64 ? large : small).push_back(f);
-    g_pending.clear();
+    auto it = g_queues.find(stream);
+    if (it == g_queues.end()) return PTOPS_OK;
+    for (const PendingFold& f : it->second.pending) (f.S > 64 ? large : small).push_back(f);
+    it->second.pending.clear();
+    if (!it->second.defer) g_queues.erase(it);
   }
   int rc = launch_batches<16>(small, stream);
   if (rc != PTOPS_OK) return rc;

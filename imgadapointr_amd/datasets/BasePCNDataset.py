@@ -45,6 +45,10 @@ class BasePCNDataset(data.Dataset):
         self.include_images = include_images
         self.num_imgs_per_obj = num_imgs_per_obj
         self.include_segmentation = include_segmentation
+        # `views` (dataset `others`, e.g. others: {subset: test, views: 12}): keep that many of the sampled views per
+        # object and return them as [V,3,224,224] - the README's 6 / 12 "random viewing points" evaluation
+        # (README.md:80-85); 1 = the released code's behaviour (one surviving view, BasePCNDataset.py:72-75)
+        self.views = int(getattr(config, 'views', 1) or 1)
         if include_images:
             self.img_path = config.IMG_PATH
             self.img_idxs = list(range(24))
@@ -80,8 +84,11 @@ class BasePCNDataset(data.Dataset):
                 if self.include_images:
                     # the reference samples num_imgs_per_obj views but keeps only the last one
                     # (BasePCNDataset.py:72-75): one view per object survives
-                    img_idx = random.sample(self.img_idxs, self.num_imgs_per_obj)[-1]
-                    item['img_path'] = self._fmt(self.img_path, subset, dc['taxonomy_id'], s, img_idx)
+                    sample = random.sample(self.img_idxs, max(self.num_imgs_per_obj, self.views))
+                    item['img_path'] = self._fmt(self.img_path, subset, dc['taxonomy_id'], s, sample[-1])
+                    if self.views > 1:
+                        item['img_paths'] = [self._fmt(self.img_path, subset, dc['taxonomy_id'], s, i)
+                                             for i in sample[-self.views:]]
                 if self.include_segmentation:
                     cls_vec = np.zeros(16)
                     if dc['taxonomy_id'] in self.SEG_LIST:
@@ -103,7 +110,10 @@ class BasePCNDataset(data.Dataset):
             item = self.transforms(item)
         out = (item['partial'], item['gt'])
         if self.include_images:
-            out = out + (load_image_224(sample['img_path']),)
+            if self.views > 1:
+                out = out + (torch.stack([load_image_224(p) for p in sample['img_paths']]),)
+            else:
+                out = out + (load_image_224(sample['img_path']),)
         if 'cls_vec' in sample:
             out = out + (torch.from_numpy(sample['cls_vec']).float(),)
         return sample['taxonomy_id'], sample['model_id'], out

@@ -57,6 +57,8 @@ def _linear_tokens(x, weight, bias):
     if (x.is_cuda and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
             and _native.backend_for_testing() is None and x.size(0) >= 2048):
         return _LinearFn.apply(x, weight, bias)
+    if bias is not None and torch.is_grad_enabled():
+        _native.fold_mark_plain(bias.data_ptr())                 # plain autograd path: see _native.deferred_folds
     return torch.nn.functional.linear(x, weight, bias)
 
 
@@ -118,9 +120,18 @@ class PCTransformer(nn.Module):
         """xyz [B,N,3] -> (q [B,M,C], coarse [B,M,3], denoise_length).
 
         `denoise_noise` ([B,64,3], optional) replaces the random jitter of the denoise seeds so
-        that a training forward can be reproduced from a fixture."""
+        that a training forward can be reproduced from a fixture.
+
+        Multi-view (the README's 6 / 12-view protocol, README.md:80-85): `img` may be [B,V,3,H,W].  Everything up to
+        the point encoder's output does not depend on the image, so it runs ONCE per object; its tokens are then
+        repeated per view and the fusion, query generation, decoder and heads run on B*V samples (object-major order
+        b*V + v, the order of `img.flatten(0, 1)`).  In eval mode the result equals V separate forwards."""
         bs = xyz.size(0)
         xyz = xyz.contiguous()
+        views = 1
+        if img is not None and img.dim() == 5:
+            views = img.size(1)
+            img = img.flatten(0, 1)
         n_seed = self.num_query // 2
         need = max(self.center_num[0], n_seed, self.denoise_num if self.training else 0)
         fps_idx = pointnet2_utils.furthest_point_sample(xyz, need)        # one run, three uses
@@ -130,6 +141,11 @@ class PCTransformer(nn.Module):
         pe = self.pos_embed(coor)
         x = self.input_proj(f)
         x = self.encoder(x + pe, coor)
+        if views > 1:
+            rep = lambda t: t.repeat_interleave(views, dim=0)            # noqa: E731  (backward sums over the views)
+            x, coor, xyz_cf, fps_idx = rep(x), rep(coor), rep(xyz_cf), rep(fps_idx)
+            cls_vec = rep(cls_vec) if cls_vec is not None else None
+            bs = bs * views
         x = self.fuse_encoder_tokens(x, coor, img, cls_vec)
         global_feature = self.increase_dim(x)
         global_feature = max_over_tokens(global_feature)                   # [B,1024]
@@ -226,6 +242,9 @@ class AdaPoinTr(nn.Module):
         """(loss_denoised, loss_recon), AdaPoinTr.py:193-216."""
         pred_coarse, denoised_coarse, denoised_fine, pred_fine = ret
         assert pred_fine.size(1) == gt.size(1)
+        if pred_fine.size(0) != gt.size(0):             # multi-view batch: V predictions per ground-truth cloud
+            assert pred_fine.size(0) % gt.size(0) == 0
+            gt = gt.repeat_interleave(pred_fine.size(0) // gt.size(0), dim=0)
         # denoise target: the `factor` nearest gt points of every denoise seed
         idx = knn_idx(self.factor, gt, denoised_coarse)                    # [B,64,factor]
         denoised_target = index_points(gt, idx).reshape(gt.size(0), -1, 3)

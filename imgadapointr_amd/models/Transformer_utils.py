@@ -58,6 +58,8 @@ def linear_on_broadcast_concat(lin, g, x):
     if not SPLIT_BROADCAST_LINEAR:
         return lin(torch.cat([g.unsqueeze(1).expand(-1, x.size(1), -1), x], dim=-1))
     G = g.size(-1)
+    if lin.bias is not None and torch.is_grad_enabled():
+        _native.fold_mark_plain(lin.bias.data_ptr())            # plain autograd path: see _native.deferred_folds
     per_cloud = F.linear(g, lin.weight[:, :G], lin.bias)        # [B,O]
     return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
 
@@ -231,6 +233,8 @@ class Linear(nn.Linear):
             return _LinearFn.apply(x, self.weight, self.bias)
         if not torch.is_grad_enabled():
             return linear_forward(x, self.weight, self.bias)      # validation / inference: same kernels as training
+        if self.bias is not None:
+            _native.fold_mark_plain(self.bias.data_ptr())         # plain autograd path: see _native.deferred_folds
         return F.linear(x, self.weight, self.bias)
 
 
@@ -262,6 +266,8 @@ class LayerNorm(nn.LayerNorm):
         if (FAST_LAYER_NORM and len(self.normalized_shape) == 1 and _native.backend_for_testing() is None
                 and _native.layer_norm_supported(x, self.weight, self.bias) and x.numel() >= 1 << 16):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        if torch.is_grad_enabled() and self.weight is not None:
+            _native.fold_mark_plain(self.weight.data_ptr())
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
 
 

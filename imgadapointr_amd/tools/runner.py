@@ -84,7 +84,8 @@ class TrainStep:
             self.ddp.set_sync(self._num_iter + 1 == self.step_per_update)
         # the first backward after zero_grad hands its gradients over unread (`.grad` is None), so the tiny fold launches
         # of the bias / LayerNorm gradients can be queued and run batched (include/ptops.h, deferred folds)
-        with (_native.deferred_folds() if (self._num_iter == 0 and DEFER_FOLDS) else contextlib.nullcontext()):
+        with (_native.deferred_folds(self.params, partial.device) if (self._num_iter == 0 and DEFER_FOLDS and partial.is_cuda)
+              else contextlib.nullcontext()):
             (sparse_loss + dense_loss).backward()
         self._num_iter += 1
         if self._num_iter == self.step_per_update:
@@ -243,6 +244,8 @@ def validate(base_model, test_dataloader, epoch, ChamferDisL1, ChamferDisL2, val
             partial, gt, extra = unpack_batch(dataset_name, data, device)
             ret = forward(partial, *extra)
             coarse_points, dense_points = ret[0], ret[-1]
+            if dense_points.size(0) != gt.size(0):      # multi-view batch: V completions per ground-truth cloud
+                gt = gt.repeat_interleave(dense_points.size(0) // gt.size(0), dim=0)
             vals = [ChamferDisL1(coarse_points, gt), ChamferDisL2(coarse_points, gt),
                     ChamferDisL1(dense_points, gt), ChamferDisL2(dense_points, gt)]
             vals += Metrics.get(dense_points, gt)

@@ -4,9 +4,12 @@
  *
  * Every entry point takes raw DEVICE pointers, explicit sizes and an explicit
  * hipStream_t (passed as void* so that this header needs no HIP include), does no
- * hidden allocation, keeps no global state, launches on the given stream and
- * returns an int status (PTOPS_OK or a negative PTOPS_E* code).  Scratch memory is
- * caller-provided; the *_workspace_bytes helpers say how much.
+ * hidden allocation, launches on the given stream and returns an int status
+ * (PTOPS_OK or a negative PTOPS_E* code).  Scratch memory is caller-provided; the
+ * *_workspace_bytes helpers say how much.  The library keeps no state between calls
+ * with one documented exception: the per-stream queues of deferred folds
+ * (ptops_fold_defer / ptops_fold_flush below), which exist only while a caller has
+ * switched deferral on for a stream.
  *
  * Each function names the reference interface it replaces (paths relative to the
  * reference repository mmkuznecov/ImgAdaPoinTr).
@@ -294,14 +297,24 @@ int ptops_edge_norm_backward(const float* grad_out, const float* ysel, const flo
 size_t ptops_colsum_workspace_bytes(int M, int N);
 int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
 
+/* A/B switches of the library (PTOPS_ATTN_FWD_F32, PTOPS_ATTN_BWD_F32, PTOPS_ATTN_FWD_WAVES, PTOPS_ATTN_DKV_WAVES,
+ * PTOPS_ATTN_QSPLIT, PTOPS_GEMM_PINGPONG): each is initialised ONCE from the environment variable of the same name
+ * and afterwards changes only through ptops_set_option (returns the previous value, -1 for an unknown name), so that
+ * a benchmark's label and the kernel that ran agree.  Benchmarking / test aid, not a tuning interface. */
+int ptops_set_option(const char* name, int value);
+int ptops_get_option(const char* name);
+
 /* Deferred folds.  ptops_colsum, ptops_layer_norm_backward and ptops_gelu_backward_colsum end with a tiny launch that
  * adds their partial rows (115 such launches per AdaPoinTr backward, 5.5 us each).  Their results are leaf gradients
  * (bias / LayerNorm weight gradients) nobody reads before the end of backward, so a training loop may switch
  * deferral on around backward: the folds are queued and ptops_fold_flush runs all of them in one or two launches,
- * with the summation order of the immediate launch.  While deferral is on the CALLER must keep every such call's
- * workspace and output alive and unread until the flush (so give each call its own workspace).
- * ptops_fold_defer returns the number of folds still queued; switching off does not flush. */
-int ptops_fold_defer(int on);
+ * with the summation order of the immediate launch.  Deferral is per STREAM: ptops_fold_defer(stream, mode) affects only
+ * folds launched on that stream (mode 0 off, 1 on, 2 on + every queued output is filled with NaN until the flush
+ * writes it - a debug aid that makes a premature read visible); ptops_fold_flush(stream) runs that stream's queue.
+ * While deferral is on the CALLER must keep every such call's workspace and output alive and unread until the flush
+ * (so give each call its own workspace).  ptops_fold_defer returns the number of folds still queued on the stream;
+ * switching off does not flush. */
+int ptops_fold_defer(void* stream, int mode);
 int ptops_fold_flush(void* stream);
 
 /* ---------------------------------------------------------- max over tokens --

@@ -559,3 +559,48 @@ def check_trainstep(case, device):
         assert all(p.grad is None for p in model.base_model.segmentator.parameters())
     return dict(out=d_out, loss_x1000=d_loss, grad_total_rel=abs(total - want_total) / want_total, grad_sample_rel=d_norm,
                 grad_vec_rel=max(d_vec.values()), after_far_frac=far / n_el, seg_running_mean=d_rm)
+
+
+def check_multi_view(device, views=3):
+    """The multi-view batch ([B,V,3,224,224] renders, README.md:80-85 protocol; point branch evaluated once per
+    object) against V separate single-view forwards: eval outputs, and in train mode the loss of the folded batch
+    against the mean of the per-view losses (same jitter per view; the ResNet BatchNorms are put in eval mode for
+    this comparison because batch statistics over B*V images differ from those over B by construction)."""
+    from golden_util import synthetic_batch, synthetic_image
+    model, _ = build_img_model(device)
+    B = 2
+    partial, gt = synthetic_batch(B, 2048, 16384, seed=61, structured=True)
+    partial, gt = t(partial, device), t(gt, device)
+    imgs = t(synthetic_image(B * views, seed=62).reshape(B, views, 3, 224, 224), device)
+    model.eval()
+    with torch.no_grad():
+        coarse, fine = model(partial, imgs)
+        assert coarse.shape == (B * views, 512, 3) and fine.shape == (B * views, 16384, 3)
+        d = 0.0
+        for v in range(views):
+            c1, f1 = model(partial, imgs[:, v].contiguous())
+            d = max(d, float((coarse[v::views] - c1).abs().max()), float((fine[v::views] - f1).abs().max()))
+    assert d < 2e-5, d
+    # train mode: losses and the gradient that reaches the shared point branch
+    model.train()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.eval()
+    noise = (torch.randn(B, 64, 3, generator=torch.Generator().manual_seed(5)) * 0.01).clamp_(-0.05, 0.05).to(device)
+    ret = model(partial, imgs, denoise_noise=noise.repeat_interleave(views, 0))
+    l_den, l_rec = model.get_loss(ret, gt, 7)
+    (l_den + l_rec).backward()
+    w = model.base_model.grouper.input_trans.weight
+    g_folded = w.grad.detach().clone()
+    model.zero_grad(set_to_none=True)
+    acc = [0.0, 0.0]
+    for v in range(views):
+        r = model(partial, imgs[:, v].contiguous(), denoise_noise=noise)
+        a, b = model.get_loss(r, gt, 7)
+        ((a + b) / views).backward()
+        acc[0] += a.item() / views
+        acc[1] += b.item() / views
+    d_loss = (abs(l_den.item() - acc[0]), abs(l_rec.item() - acc[1]))
+    d_grad = float((g_folded - w.grad).norm() / w.grad.norm())
+    assert max(d_loss) < 2e-6 and d_grad < 2e-3, (d_loss, d_grad)
+    return d, d_loss, d_grad

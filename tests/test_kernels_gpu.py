@@ -938,6 +938,81 @@ def test_deferred_folds_match_immediate_ones(native):
         assert torch.equal(a, b)
 
 
+def test_deferred_folds_guards(native):
+    """The failure modes the deferral could have, each with the queued outputs POISONED (NaN until the
+    flush), so that a gradient adopted or added before its fold ran cannot pass:
+      * a shared Linear / LayerNorm that is applied once through the deferring path (>= 2048 rows) and once through the
+        plain aten path (few rows) in the same graph - the engine adds the two gradients at once;
+      * `linear_on_broadcast_concat` on a parameter that also feeds a deferring Linear;
+      * a stale `.grad` at the start of backward (an exception between backward and zero_grad): deferral is refused;
+      * deferral is per stream: producers on another stream are not queued."""
+    import contextlib
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(11)
+    lin, norm = TU.Linear(384, 384).cuda(), TU.LayerNorm(384).cuda()
+    big = torch.randn(8, 576, 384, device="cuda", requires_grad=True)        # 4608 rows: _LinearFn / _LayerNormFn
+    small = torch.randn(2, 64, 384, device="cuda", requires_grad=True)       # 128 rows: F.linear / F.layer_norm
+    g = torch.randn(8, 384, device="cuda")
+    params = list(lin.parameters()) + list(norm.parameters())
+
+    def graph():
+        a = lin(norm(big))                                                   # deferring producers
+        b = lin(norm(small))                                                 # plain paths, same parameters
+        return a.square().mean() + b.square().mean()
+
+    def run(defer, order):
+        for p in params:
+            p.grad = None
+        loss = graph() if order == 0 else (lin(norm(small)).square().mean() + lin(norm(big)).square().mean())
+        with (native.deferred_folds(params) if defer else contextlib.nullcontext()):
+            loss.backward()
+        assert not native._fold_keepalive
+        return [p.grad.clone() for p in params]
+
+    old = native.FOLD_POISON
+    native.FOLD_POISON = True
+    try:
+        for order in (0, 1):
+            ref, got = run(False, order), run(True, order)
+            for a, b in zip(ref, got):
+                assert torch.isfinite(b).all() and torch.equal(a, b)
+        # broadcast-concat Linear whose bias also belongs to a deferring call
+        cat_lin = TU.Linear(384 + 384, 384).cuda()
+
+        def run_cat(defer):
+            cat_lin.zero_grad(set_to_none=True)
+            y = TU.linear_on_broadcast_concat(cat_lin, g, big)               # plain path on cat_lin.bias
+            z = cat_lin(torch.cat([big, big], -1))                           # deferring path on the same bias
+            with (native.deferred_folds(list(cat_lin.parameters())) if defer else contextlib.nullcontext()):
+                (y.square().mean() + z.square().mean()).backward()
+            return [p.grad.clone() for p in cat_lin.parameters()]
+
+        for a, b in zip(run_cat(False), run_cat(True)):
+            assert torch.isfinite(b).all() and torch.equal(a, b)
+        # stale .grad: accumulate-into-existing must not meet a queued buffer -> the context does not defer
+        run(False, 0)
+        stale = [p.grad.clone() for p in params]
+        loss = graph()
+        with native.deferred_folds(params):
+            assert not native._fold_deferred
+            loss.backward()
+        accumulated = [p.grad.clone() for p in params]
+        fresh = run(False, 0)
+        for s0, acc, s1 in zip(stale, accumulated, fresh):
+            assert torch.isfinite(acc).all() and torch.allclose(acc, s0 + s1, rtol=1e-5, atol=1e-7)
+        # per-stream: deferral on the current stream does not capture a producer running on a side stream
+        side = torch.cuda.Stream()
+        xs = torch.randn(4096, 384, device="cuda")
+        torch.cuda.synchronize()
+        with native.deferred_folds():
+            with torch.cuda.stream(side):
+                cs = native.colsum(xs)
+            side.synchronize()
+            assert torch.isfinite(cs).all() and torch.allclose(cs, xs.sum(0), rtol=1e-4, atol=1e-3)
+    finally:
+        native.FOLD_POISON = old
+
+
 def test_clip_adamw_matches_torch(native):
     """ClipAdamW.step_clipped == clip_grad_norm_ + torch.optim.AdamW.step over several steps: two weight-decay groups,
     an lr change, a parameter without gradient on some steps, tensor sizes around the 4096-element chunk, clipping
@@ -984,6 +1059,18 @@ def test_clip_adamw_matches_torch(native):
     # a state_dict round trip through the stock class
     other = torch.optim.AdamW(groups([p.detach().clone().requires_grad_(True) for p in our_p]), lr=1e-2)
     other.load_state_dict(our.state_dict())
+    # a NaN gradient: clip_grad_norm_ + step() of the reference turn every parameter into NaN at once (NaN norm -> NaN
+    # coefficient); the fused step must not hide the blow-up behind a coefficient of 1
+    for a, b in zip(ref_p, our_p):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    ref_p[3].grad[7] = float("nan")
+    our_p[3].grad[7] = float("nan")
+    torch.nn.utils.clip_grad_norm_(ref_p, 10.0, norm_type=2)
+    ref.step()
+    assert torch.isnan(our.step_clipped(10.0))
+    for a, b in zip(ref_p, our_p):
+        assert torch.isnan(a).all() and torch.isnan(b).all()
 
 
 def test_mlp_with_gelu_in_the_gemm_epilogue(native):

@@ -128,3 +128,7 @@ def test_analytic_normals_eigenvector_matches_eigh():
 def test_full_train_step_of_the_fused_families_matches_reference(case):
     """BASELINE configs[2] / [4] and SegEncAdaPoinTr: one production TrainStep at B = 2 vs the reference fixture."""
     print(pc.check_trainstep(case, "cpu"))
+
+
+def test_multi_view_batch_equals_separate_views():
+    print(pc.check_multi_view("cpu", views=2))

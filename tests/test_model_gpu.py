@@ -72,3 +72,7 @@ def test_full_train_step_of_the_fused_families_matches_reference(case):
     """BASELINE configs[2] / [4] and SegEncAdaPoinTr: one production TrainStep (split-bf16 GEMMs and attention, deferred
     folds, fused clip + AdamW) at B = 2 on the HIP path vs the reference fixture."""
     print(pc.check_trainstep(case, "cuda"))
+
+
+def test_multi_view_batch_equals_separate_views():
+    print(pc.check_multi_view("cuda", views=3))
