@@ -305,13 +305,27 @@ class PrimitiveProbe:
             recs = self.rec[kind]
             if not recs:
                 continue
+            # HBM traffic and pipe activity: separate rocprofv3 --pmc passes over the same launches
+            # (benchmarks/primitives_only.py, benchmarks/pmc_passes.sh), averages per launch
+            pmc_file = os.path.join(ROOT, "profiles", "round3", f"{kind}_pmc.json")
+            pmc = {}
+            if os.path.exists(pmc_file):
+                with open(pmc_file) as fh:
+                    ks = json.load(fh).get("kernels", [])
+                pmc = ks[0].get("derived", {}) if ks else {}
             ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
             nbytes, work = sum(r[2] for r in recs), sum(r[3] for r in recs)
             gbs = nbytes / (ms * 1e-3) / 1e9
             out[kind] = {"launches_per_step": len(recs), "ms_per_step": round(ms, 3),
                          "work_rate": round(work / (ms * 1e-3) / 1e9, 1), "work_unit": unit,
                          "hbm": {"achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_step": nbytes}}
+                                 "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_step": nbytes},
+                         "traffic": (round(pmc["hbm_traffic_bytes"] * len(recs)) if "hbm_traffic_bytes" in pmc else None),
+                         "traffic_source": f"profiles/round3/{kind}_pmc.json (per-launch average x launches; FETCH_SIZE x 2 "
+                                           "upper bound + WRITE_SIZE)",
+                         "pmc": {k: round(pmc[k], 4) for k in ("valu_busy_fraction", "salu_busy_fraction",
+                                                               "waves_resident_per_simd", "sq_wait_any_share_of_wave_cycles",
+                                                               "lds_issue_busy_fraction") if k in pmc}}
         return out
 
 

@@ -38,6 +38,8 @@ def _declare(lib):
         "ptops_chamfer_forward_ex": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P]),
         "ptops_chamfer_sweep_available": (c_int, [c_int] * 3),
         "ptops_chamfer_backward": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P]),
+        "ptops_chamfer_backward_det_workspace_bytes": (c_size, [c_int] * 3),
+        "ptops_chamfer_backward_det": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P, c_size, P]),
         "ptops_furthest_point_sample": (c_int, [P, c_int, c_int, c_int, P, P]),
         "ptops_gather_forward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_gather_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
@@ -100,7 +102,8 @@ def _declare(lib):
 EXPORTS = (
     "ptops_abi_version", "ptops_last_error", "ptops_chamfer_forward_workspace_bytes",
     "ptops_chamfer_forward", "ptops_chamfer_forward_ex", "ptops_chamfer_sweep_available",
-    "ptops_chamfer_backward", "ptops_furthest_point_sample",
+    "ptops_chamfer_backward", "ptops_chamfer_backward_det_workspace_bytes", "ptops_chamfer_backward_det",
+    "ptops_furthest_point_sample",
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
@@ -301,8 +304,14 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
     return dist1, dist2, idx1, idx2
 
 
-def chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
-    """chamfer.backward (extensions/chamfer_dist/chamfer_cuda.cpp:27-34)."""
+# True: scatter-add backward passes with a fixed summation order (bit-identical gradients from run to run) where the
+# library has one: Chamfer (max(n, m) <= 16384).  False: the reference's atomicAdd form everywhere.
+DETERMINISTIC_BACKWARD = os.environ.get("PTOPS_DETERMINISTIC_BACKWARD", "1") != "0"
+
+
+def chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2, deterministic=None):
+    """chamfer.backward (extensions/chamfer_dist/chamfer_cuda.cpp:27-34).  `deterministic` (default: the module
+    switch): own term + neighbour terms by ascending index instead of atomicAdd arrival order."""
     if _test_backend is not None:
         return _test_backend.chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
     _check(xyz1, "xyz1", torch.float32, 3)
@@ -320,8 +329,17 @@ def chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
     with torch.cuda.device(dev):
         g1 = torch.empty_like(xyz1)
         g2 = torch.empty_like(xyz2)
-        _call("ptops_chamfer_backward", _ptr(xyz1), _ptr(xyz2), _ptr(idx1), _ptr(idx2),
-              _ptr(grad_dist1), _ptr(grad_dist2), B, n, m, _ptr(g1), _ptr(g2), _stream(xyz1))
+        det = DETERMINISTIC_BACKWARD if deterministic is None else deterministic
+        if det and B > 0 and 0 < n <= 16384 and 0 < m <= 16384:
+            stream = torch.cuda.current_stream(dev)
+            need = load().ptops_chamfer_backward_det_workspace_bytes(B, n, m)
+            ws = _scratch(dev, stream, need)
+            _call("ptops_chamfer_backward_det", _ptr(xyz1), _ptr(xyz2), _ptr(idx1), _ptr(idx2), _ptr(grad_dist1),
+                  _ptr(grad_dist2), B, n, m, _ptr(g1), _ptr(g2), _ptr(ws), ctypes.c_size_t(need),
+                  ctypes.c_void_p(stream.cuda_stream))
+        else:
+            _call("ptops_chamfer_backward", _ptr(xyz1), _ptr(xyz2), _ptr(idx1), _ptr(idx2),
+                  _ptr(grad_dist1), _ptr(grad_dist2), B, n, m, _ptr(g1), _ptr(g2), _stream(xyz1))
     return g1, g2
 
 

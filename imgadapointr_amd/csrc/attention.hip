@@ -45,6 +45,7 @@ struct AttnArgs {
   int H, Nq, Nk;
   int split_q, limit_k;  // queries < split_q attend to keys < limit_k; the others to all Nk
   float scale_log2e;
+  int xcd_remap;         // split3 kernels: XCD-contiguous job order (xcd_job below); 0 = plain blockIdx order (A/B)
 };
 
 __device__ __forceinline__ float other_half(float x) {
@@ -225,6 +226,22 @@ __device__ __forceinline__ Pieces3 split8(const float (&x)[8]) {
   return p;
 }
 
+// Workgroups b and b + 8 share an XCD (round-robin dispatch, speed only): hand every XCD one contiguous range of the job
+// list (job = head-major, tile-minor), so that the workgroups of one (batch, head) read its K / V (or Q / dO) tiles through
+// ONE L2 instead of up to five.  Bijective for any grid; placement never affects results.
+__device__ __forceinline__ void xcd_job(int remap, int& bx, int& bh) {
+  if (!remap) {
+    bx = blockIdx.x, bh = blockIdx.y;
+    return;
+  }
+  const int gx = gridDim.x, nwg = gx * gridDim.y;
+  const int orig = blockIdx.x + gx * blockIdx.y;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  bh = job / gx;
+  bx = job - bh * gx;
+}
+
 // the six piece products, smallest first: (piece of A, piece of B)
 #define PTOPS_SPLIT3_TERMS(F) F(2, 0) F(1, 1) F(0, 2) F(1, 0) F(0, 1) F(0, 0)
 
@@ -236,14 +253,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
-  const int q0 = (blockIdx.x * W + wave) * 32;
+  int bx, bh;
+  xcd_job(a.xcd_remap, bx, bh);
+  const int b = bh / a.H, head = bh % a.H;
+  const int q0 = (bx * W + wave) * 32;
   const bool active = q0 < a.Nq;  // wave-uniform
   const float* qb = a.q + b * a.q_sb + head * a.q_sh;
   const float* kb = a.k + b * a.k_sb + head * a.k_sh;
   const float* vb = a.v + b * a.v_sb + head * a.v_sh;
 
-  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q0 = bx * W * 32;
   const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
   const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
   const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
@@ -402,6 +421,7 @@ struct AttnBwdArgs {
   int H, Nq, Nk;
   int split_q, limit_k;
   float scale, scale_log2e;
+  int xcd_remap;
 };
 
 // accumulator (rows = dims, column = lane&31) -> 64 contiguous floats of row `dst`, times `mul`
@@ -708,13 +728,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
-  const int q0 = (blockIdx.x * W + wave) * 32;
+  int bx, bh;
+  xcd_job(a.xcd_remap, bx, bh);
+  const int b = bh / a.H, head = bh % a.H;
+  const int q0 = (bx * W + wave) * 32;
   const bool active = q0 < a.Nq;
   const float* kb = a.k + b * a.k_sb + head * a.k_sh;
   const float* vb = a.v + b * a.v_sb + head * a.v_sh;
 
-  const int blk_q0 = blockIdx.x * W * 32;
+  const int blk_q0 = bx * W * 32;
   const int blk_q1 = min(blk_q0 + W * 32, a.Nq);
   const int blk_keys = (blk_q1 > a.split_q) ? a.Nk : a.limit_k;
   const int my_keys = active ? ((q0 >= a.split_q) ? a.Nk : a.limit_k) : 0;
@@ -866,8 +888,10 @@ __global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh % a.H;
-  const int k0 = (blockIdx.x * W + wave) * 32;
+  int bx, bh;
+  xcd_job(a.xcd_remap, bx, bh);
+  const int b = bh / a.H, head = bh % a.H;
+  const int k0 = (bx * W + wave) * 32;
   const bool active = k0 < a.Nk;
   const float* qb = a.q + b * a.q_sb + head * a.q_sh;
   const float* dob = a.dout + ((long long)b * a.Nq * a.H + head) * kD;  // row stride H*64
@@ -876,7 +900,7 @@ __global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs
   const long long do_sn = (long long)a.H * kD;
 
   // query tiles this workgroup walks: keys >= limit_k are seen only by queries >= split_q
-  const int blk_k0 = blockIdx.x * W * 32;
+  const int blk_k0 = bx * W * 32;
   const int blk_qstart = (blk_k0 >= a.limit_k) ? a.split_q : 0;
   const int my_qstart = active ? ((k0 >= a.limit_k) ? a.split_q : 0) : a.Nq;
 
@@ -1358,6 +1382,7 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
   a.scale_log2e = scale * 1.4426950408889634f;
+  a.xcd_remap = !ptops::option("PTOPS_ATTN_NO_XCD_REMAP");
   const int tiles = Nq / 32;
   // Four waves per workgroup whenever there are four query tiles, a last workgroup with idle waves included
   // (576 queries = 18 tiles -> 5 workgroups per head): the 4-wave instantiation fits 128 VGPRs, so four workgroups
@@ -1418,6 +1443,7 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
   a.dv_sb = dv_strides[0]; a.dv_sh = dv_strides[1]; a.dv_sn = dv_strides[2];
   a.H = H; a.Nq = Nq; a.Nk = Nk; a.split_q = split_q; a.limit_k = limit_k;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  a.xcd_remap = !ptops::option("PTOPS_ATTN_NO_XCD_REMAP");
   // >= 4 tiles on both sides: the bf16-matrix-pipe pair (fp32-accurate three-piece split); PTOPS_ATTN_BWD_F32=1 keeps
   // the f32-MFMA kernels for A/B runs
   const bool f32_only = ptops::option("PTOPS_ATTN_BWD_F32") != 0;
@@ -1526,6 +1552,7 @@ PTOPS_API int ptops_attention_backward_fused(const float* q, const float* k, con
   AttnFusedArgs fa;
   AttnBwdArgs& a = fa.a;
   a.q = q; a.k = k; a.v = v; a.o = out; a.dout = dout; a.lse = lse; a.delta = nullptr; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.xcd_remap = 0;
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sn = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sn = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sn = v_strides[2];

@@ -235,6 +235,177 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
   }
 }
 
+// ---- deterministic backward (round 3): the neighbour half without float atomics ------------------------------------
+// The reference (chamfer.cu:193-198) and chamfer_grad_kernel<true> add the neighbour terms with atomicAdd, i.e. in
+// arrival order: gradients differ in the last bits from run to run.  Here the nearest-neighbour map is transposed once
+// per call (for every point the list of points of the other cloud that chose it, ASCENDING) and every point sums its
+// own term and then its list in that fixed order: bit-identical results on every run, no zero-fill, no atomics.
+//
+// chamfer_csr_kernel: one workgroup per (cloud, direction).  Counting sort in LDS (integer atomics only decide slots,
+// not sums), rows put in ascending order afterwards: short rows (<= 32 entries) by rank inside the row, long rows - a
+// prediction collapsed onto few target points sends thousands of points to one neighbour - by an ordered re-scan of the
+// index array with ballot / popcount, one wave per long row (no O(n^2) path for any input).
+constexpr int kCsrT = 1024;
+constexpr int kCsrShort = 32;
+
+__global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
+                                                            int n, int m, int32_t* __restrict__ rowptr1, int32_t* __restrict__ tmp1,
+                                                            int32_t* __restrict__ col1, int32_t* __restrict__ rowptr2,
+                                                            int32_t* __restrict__ tmp2, int32_t* __restrict__ col2) {
+  extern __shared__ __attribute__((aligned(16))) int csm[];   // cnt[nc] | cur[nc] | part[kCsrT]
+  const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+  const int nq = dir ? m : n, nc = dir ? n : m;               // nq entries (points that chose), nc rows (points chosen)
+  const int32_t* __restrict__ ib = (dir ? idx2 : idx1) + (size_t)b * nq;
+  int32_t* __restrict__ rp = (dir ? rowptr2 : rowptr1) + (size_t)b * (nc + 1);
+  int32_t* __restrict__ tp = (dir ? tmp2 : tmp1) + (size_t)b * nq;
+  int32_t* __restrict__ cl = (dir ? col2 : col1) + (size_t)b * nq;
+  int* cnt = csm;
+  int* cur = cnt + nc;
+  int* part = cur + nc;
+  for (int r = tid; r < nc; r += kCsrT) cnt[r] = 0;
+  __syncthreads();
+  for (int e = tid; e < nq; e += kCsrT) atomicAdd(&cnt[ib[e]], 1);
+  __syncthreads();
+  const int per = (nc + kCsrT - 1) / kCsrT;                   // exclusive scan: thread t owns rows [t*per, (t+1)*per)
+  int local = 0;
+  for (int i = 0; i < per; ++i) {
+    const int r = tid * per + i;
+    if (r < nc) local += cnt[r];
+  }
+  part[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < kCsrT; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - local;
+  for (int i = 0; i < per; ++i) {
+    const int r = tid * per + i;
+    if (r < nc) {
+      cur[r] = run;
+      rp[r] = run;
+      run += cnt[r];
+    }
+  }
+  if (tid == kCsrT - 1) rp[nc] = part[tid];
+  __syncthreads();
+  for (int e = tid; e < nq; e += kCsrT) {                     // unordered fill of the short rows' slots
+    const int r = ib[e];
+    const int pos = atomicAdd(&cur[r], 1);
+    if (cnt[r] <= kCsrShort) tp[pos] = e;
+  }
+  __syncthreads();                                            // (workgroup-scope fence: tp is re-read by other threads below)
+  for (int r = tid; r < nc; r += kCsrT) {                     // short rows: every entry to the slot of its rank
+    const int c = cnt[r];
+    if (c == 0 || c > kCsrShort) continue;
+    const int beg = cur[r] - c;
+    for (int i = 0; i < c; ++i) {
+      const int v = tp[beg + i];
+      int rank = 0;
+      for (int j = 0; j < c; ++j) rank += tp[beg + j] < v;
+      cl[beg + rank] = v;
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;                 // long rows: ordered re-scan, one wave per row
+  for (int r = wave; r < nc; r += kCsrT / 64) {
+    const int c = cnt[r];                                     // wave-uniform
+    if (c <= kCsrShort) continue;
+    int base = cur[r] - c;
+    for (int e0 = 0; e0 < nq; e0 += 64) {
+      const int e = e0 + lane;
+      const bool hit = e < nq && ib[e] == r;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) cl[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+      base += __popcll(mask);
+    }
+  }
+}
+
+// One lane per point of either cloud.  The additions happen in exactly the order of the scalar loops of the CPU oracle
+// (oracle/ptops_ref.c: pass over cloud 1, then pass over cloud 2, each adding its own term to the point and the negated
+// term to the neighbour): a point of cloud 1 = own term, then the terms of the cloud-2 points that chose it by ascending
+// index; a point of cloud 2 = the terms of the cloud-1 points that chose it by ascending index, then its own term.  Rows
+// longer than 64 are walked by the whole wave: 64 terms are computed in parallel and added one after the other in entry
+// order (readlane), so the order - and the result, bit for bit - is the same for every row length.
+__global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, const int32_t* __restrict__ idx1,
+    const int32_t* __restrict__ idx2, const float* __restrict__ gd1, const float* __restrict__ gd2, int B, int n, int m,
+    const int32_t* __restrict__ rowptr1, const int32_t* __restrict__ col1, const int32_t* __restrict__ rowptr2,
+    const int32_t* __restrict__ col2, float* __restrict__ g1, float* __restrict__ g2) {
+  const long long t1 = (long long)B * n, total = t1 + (long long)B * m;
+  const long long t = blockIdx.x * 256LL + threadIdx.x;
+  const bool live = t < total;
+  const bool second = live && t >= t1;
+  const long long e = live ? (second ? t - t1 : t) : 0;
+  const int np = second ? m : n, no = second ? n : m;
+  const int b = (int)(e / np), j = (int)(e % np);
+  const float* pb = (second ? xyz2 : xyz1) + (size_t)b * np * 3;     // my cloud
+  const float* ob = (second ? xyz1 : xyz2) + (size_t)b * no * 3;     // the other cloud
+  const float* god = (second ? gd1 : gd2) + (size_t)b * no;          // incoming gradients of the other cloud's distances
+  // rows indexed by MY cloud's points hold the points of the other cloud that chose them: built from the other
+  // direction's index array (rowptr1 / col1: rows = cloud 2, entries = cloud 1; rowptr2 / col2: rows = cloud 1)
+  const int32_t* rp = (second ? rowptr1 : rowptr2) + (size_t)b * (np + 1);
+  const int32_t* cl = (second ? col1 : col2) + (size_t)b * no;
+  float px = 0.f, py = 0.f, pz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+  int beg = 0, cnt = 0;
+  if (live) {
+    px = pb[(size_t)j * 3], py = pb[(size_t)j * 3 + 1], pz = pb[(size_t)j * 3 + 2];
+    const int j2 = (second ? idx2 : idx1)[e];
+    const float g = (second ? gd2 : gd1)[e] * 2.0f;
+    ox = g * (px - ob[(size_t)j2 * 3]), oy = g * (py - ob[(size_t)j2 * 3 + 1]), oz = g * (pz - ob[(size_t)j2 * 3 + 2]);
+    beg = rp[j];
+    cnt = rp[j + 1] - beg;
+    if (!second) ax += ox, ay += oy, az += oz;                     // cloud 1: the own term is added first
+    if (cnt <= 64) {
+      for (int i = 0; i < cnt; ++i) {
+        const int k = cl[beg + i];
+        const float gk = god[k] * 2.0f;
+        ax += -(gk * (ob[(size_t)k * 3] - px));
+        ay += -(gk * (ob[(size_t)k * 3 + 1] - py));
+        az += -(gk * (ob[(size_t)k * 3 + 2] - pz));
+      }
+    }
+  }
+  unsigned long long todo = __ballot(live && cnt > 64);
+  const int lane = threadIdx.x & 63;
+  while (todo) {                                                   // wave-uniform
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int rb = __shfl(beg, src), rc = __shfl(cnt, src);
+    const float qx = __shfl(px, src), qy = __shfl(py, src), qz = __shfl(pz, src);
+    const int sb = __shfl(b, src), ssecond = __shfl((int)second, src);
+    const int sno = ssecond ? n : m;
+    const float* sob = (ssecond ? xyz1 : xyz2) + (size_t)sb * sno * 3;
+    const float* sgod = (ssecond ? gd1 : gd2) + (size_t)sb * sno;
+    const int32_t* scl = (ssecond ? col1 : col2) + (size_t)sb * sno;
+    float sx = __shfl(ax, src), sy = __shfl(ay, src), sz = __shfl(az, src);
+    for (int i0 = 0; i0 < rc; i0 += 64) {
+      float tx = 0.f, ty = 0.f, tz = 0.f;
+      if (i0 + lane < rc) {
+        const int k = scl[rb + i0 + lane];
+        const float gk = sgod[k] * 2.0f;
+        tx = -(gk * (sob[(size_t)k * 3] - qx));
+        ty = -(gk * (sob[(size_t)k * 3 + 1] - qy));
+        tz = -(gk * (sob[(size_t)k * 3 + 2] - qz));
+      }
+      const int lim = min(64, rc - i0);
+      for (int i = 0; i < lim; ++i) {                              // strictly in entry order
+        sx += __shfl(tx, i);
+        sy += __shfl(ty, i);
+        sz += __shfl(tz, i);
+      }
+    }
+    if (lane == src) ax = sx, ay = sy, az = sz;
+  }
+  if (live) {
+    if (second) ax += ox, ay += oy, az += oz;                      // cloud 2: the own term is added last
+    float* gp = (second ? g2 : g1) + ((size_t)b * np + j) * 3;
+    gp[0] = ax, gp[1] = ay, gp[2] = az;
+  }
+}
+
 struct Plan {
   int Q;
   bool pk;
@@ -448,3 +619,53 @@ PTOPS_API int ptops_chamfer_backward(const float* xyz1, const float* xyz2, const
                      grad_dist1, grad_dist2, B, n, m, grad_xyz1, grad_xyz2);
   return ptops::check_launch("chamfer_grad_kernel");
 }
+
+// Deterministic form of ptops_chamfer_backward: same values up to the order of the float additions, but that order is
+// fixed - the order of the scalar loops of the CPU oracle - so repeated runs are bit-identical (and bit-equal to it).  Needs
+// max(n, m) <= 16384 (the transposition's counters live in LDS) - otherwise PTOPS_EINVAL, use ptops_chamfer_backward.
+PTOPS_API size_t ptops_chamfer_backward_det_workspace_bytes(int B, int n, int m) {
+  if (B <= 0 || n <= 0 || m <= 0) return 16;
+  // per direction: rowptr [B][rows + 1], unordered + ordered columns [B][entries] each
+  return sizeof(int32_t) * ((size_t)B * ((size_t)n + m + 2) + 4 * (size_t)B * ((size_t)n + m)) + 64;
+}
+
+PTOPS_API int ptops_chamfer_backward_det(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
+                                         const float* grad_dist1, const float* grad_dist2, int B, int n, int m,
+                                         float* grad_xyz1, float* grad_xyz2, void* workspace, size_t workspace_bytes,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && n >= 0 && m >= 0, "chamfer_backward_det: negative size");
+  if (B == 0) return PTOPS_OK;
+  if (n == 0 || m == 0)
+    return ptops_chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2, B, n, m, grad_xyz1, grad_xyz2, stream_);
+  PTOPS_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_dist1 && grad_dist2 && grad_xyz1 && grad_xyz2 && workspace,
+                "chamfer_backward_det: null pointer");
+  PTOPS_REQUIRE(n <= 16384 && m <= 16384, "chamfer_backward_det: clouds of at most 16384 points (n=%d m=%d)", n, m);
+  PTOPS_REQUIRE(B <= 65535, "chamfer_backward_det: B exceeds the grid limit");
+  PTOPS_REQUIRE(workspace_bytes >= ptops_chamfer_backward_det_workspace_bytes(B, n, m) && ((uintptr_t)workspace & 15) == 0,
+                "chamfer_backward_det: workspace too small or misaligned");
+  int32_t* w = (int32_t*)workspace;
+  int32_t* rowptr1 = w;                 // direction 0: rows = points of cloud 2, entries = points of cloud 1 (idx1)
+  w += (size_t)B * (m + 1);
+  int32_t* rowptr2 = w;                 // direction 1: rows = points of cloud 1, entries = points of cloud 2 (idx2)
+  w += (size_t)B * (n + 1);
+  int32_t* tmp1 = w;
+  w += (size_t)B * n;
+  int32_t* col1 = w;
+  w += (size_t)B * n;
+  int32_t* tmp2 = w;
+  w += (size_t)B * m;
+  int32_t* col2 = w;
+  const int nc_max = n > m ? n : m;
+  const size_t lds = sizeof(int) * (2 * (size_t)nc_max + kCsrT);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chamfer_csr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(chamfer_csr_kernel, dim3(B, 2), dim3(kCsrT), lds, stream, idx1, idx2, n, m, rowptr1, tmp1, col1, rowptr2,
+                     tmp2, col2);
+  int rc = ptops::check_launch("chamfer_csr_kernel");
+  if (rc != PTOPS_OK) return rc;
+  const long long total = (long long)B * ((long long)n + m);
+  hipLaunchKernelGGL(chamfer_grad_det_kernel, dim3((unsigned)ptops::ceil_div_ll(total, 256)), dim3(256), 0, stream, xyz1, xyz2,
+                     idx1, idx2, grad_dist1, grad_dist2, B, n, m, rowptr1, col1, rowptr2, col2, grad_xyz1, grad_xyz2);
+  return ptops::check_launch("chamfer_grad_det_kernel");
+}
+

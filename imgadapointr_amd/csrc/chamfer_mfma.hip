@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void chamfer_mfma_unpack_kernel(const unsigned
 }
 
 // (kTPB, 4): at most 128 registers (4 workgroups per CU); it also makes hipcc write MFMA results to VGPRs.
+template <bool PREFETCH>
 __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
   __shared__ uint4 tile[2][kEntT];   // two tiles of A operand entries, 12 KB each
 
@@ -232,35 +233,32 @@ __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
       e1 = gp[256];
       e2 = gp[512];
     }
-#pragma unroll 1
-    for (int h = 0; h < kTileSB; ++h) {
-      const int sb = tl * kTileSB + h;
-      float v[kQG];
-#pragma unroll
-      for (int g = 0; g < kQG; ++g) v[g] = INFINITY;
-#pragma unroll 1
-      for (int blk = 0; blk < kSBB; blk += 2) {   // not unrolled: unrolled, hipcc hoists all the MFMAs and spills their results
-        // Two blocks x two query groups = eight MFMAs issued back to back: the four that start an accumulation, then
-        // the four that finish one (each 128 cycles behind the MFMA it depends on).  Left to itself hipcc reuses ONE
-        // result register block and serialises MFMA -> MFMA -> 8 dependent v_min3 (matrix pipe 57 % busy).
-        const uint4* t0 = &tile[cur][(h * kSBB + blk) * kEntB];
+    if (PREFETCH) {
+      // The same work with the fragments of the NEXT block pair requested right behind the MFMAs of the current one, so
+      // that their LDS latency passes under the 32 v_min3 of the fold instead of in front of the next MFMAs (two named
+      // register sets, the two block pairs of a superblock unrolled by hand: no copies).  Only the first pair of a tile
+      // is read unprefetched (its tile became visible at the barrier just passed).
+      auto frags = [&](int pair, bf16x8& x10, bf16x8& x20, bf16x8& x11, bf16x8& x21) {
+        const uint4* t0 = &tile[cur][pair * 2 * kEntB];
         const uint4* t1 = t0 + kEntB;
-        const bf16x8 a10 = __builtin_bit_cast(bf16x8, t0[lane]);           // k-groups 0 | 1
-        const bf16x8 a20 = __builtin_bit_cast(bf16x8, t0[64 + col]);       // k-group 2 for both halves: the upper half
-        const bf16x8 a11 = __builtin_bit_cast(bf16x8, t1[lane]);           //   meets zeros in bq2
-        const bf16x8 a21 = __builtin_bit_cast(bf16x8, t1[64 + col]);
-        f32x16 r[2][kQG];
+        x10 = __builtin_bit_cast(bf16x8, t0[lane]);
+        x20 = __builtin_bit_cast(bf16x8, t0[64 + col]);
+        x11 = __builtin_bit_cast(bf16x8, t1[lane]);
+        x21 = __builtin_bit_cast(bf16x8, t1[64 + col]);
+      };
+      auto products = [&](const bf16x8& x10, const bf16x8& x20, const bf16x8& x11, const bf16x8& x21, f32x16 (&r)[2][kQG]) {
 #pragma unroll
         for (int g = 0; g < kQG; ++g) {
-          r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, bq1[g], zero16, 0, 0, 0);
-          r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, bq1[g], zero16, 0, 0, 0);
+          r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x10, bq1[g], zero16, 0, 0, 0);
+          r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x11, bq1[g], zero16, 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < kQG; ++g) {
-          r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, bq2[g], r[0][g], 0, 0, 0);
-          r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, bq2[g], r[1][g], 0, 0, 0);
+          r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x20, bq2[g], r[0][g], 0, 0, 0);
+          r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x21, bq2[g], r[1][g], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto fold = [&](const f32x16 (&r)[2][kQG], float (&v)[kQG]) {
 #pragma unroll
         for (int g = 0; g < kQG; ++g) {
           float wa = min3(r[0][g][0], r[0][g][1], r[0][g][2]);
@@ -273,20 +271,98 @@ __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
           v[g] = min3(v[g], wa, wb);
           v[g] = min3(v[g], r[0][g][15], r[1][g][15]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      bf16x8 a10, a20, a11, a21, b10, b20, b11, b21;
+      frags(0, a10, a20, a11, a21);
+#pragma unroll 1
+      for (int h = 0; h < kTileSB; ++h) {
+        const int sb = tl * kTileSB + h;
+        float v[kQG];
 #pragma unroll
-      for (int g = 0; g < kQG; ++g) {
-        // sorted insertion of (v, sb) into the three smallest superblock minima (v_med3 x2, 2 compares, 4 selects)
-        const float o1 = m1[g], o2 = m2[g], o3 = m3[g];
-        const int ob1 = b1[g], ob2 = b2[g];
-        const bool lt1 = v[g] < o1, lt2 = v[g] < o2;
-        const int t2 = lt2 ? sb : ob2;
-        m3[g] = __builtin_amdgcn_fmed3f(o2, o3, v[g]);
-        m2[g] = __builtin_amdgcn_fmed3f(o1, o2, v[g]);
-        m1[g] = lt1 ? v[g] : o1;
-        b2[g] = lt1 ? ob1 : t2;
-        b1[g] = lt1 ? sb : ob1;
+        for (int g = 0; g < kQG; ++g) v[g] = INFINITY;
+        f32x16 r[2][kQG];
+        products(a10, a20, a11, a21, r);
+        frags(2 * h + 1, b10, b20, b11, b21);                 // second pair of this superblock
+        __builtin_amdgcn_sched_barrier(0);
+        fold(r, v);
+        // hipcc would hoist the next eight MFMAs above this fold (second result set, spills in the loop): make their
+        // operands nominally depend on the fold's result.  Costs no instruction.
+        asm volatile("" : "+v"(b10), "+v"(b20), "+v"(b11), "+v"(b21) : "v"(v[0]), "v"(v[1]));
+        products(b10, b20, b11, b21, r);
+        if (h + 1 < kTileSB) frags(2 * h + 2, a10, a20, a11, a21);   // first pair of the next superblock of this tile
+        __builtin_amdgcn_sched_barrier(0);
+        fold(r, v);
+        asm volatile("" : "+v"(a10), "+v"(a20), "+v"(a11), "+v"(a21) : "v"(v[0]), "v"(v[1]));
+#pragma unroll
+        for (int g = 0; g < kQG; ++g) {
+          const float o1 = m1[g], o2 = m2[g], o3 = m3[g];
+          const int ob1 = b1[g], ob2 = b2[g];
+          const bool lt1 = v[g] < o1, lt2 = v[g] < o2;
+          const int t2 = lt2 ? sb : ob2;
+          m3[g] = __builtin_amdgcn_fmed3f(o2, o3, v[g]);
+          m2[g] = __builtin_amdgcn_fmed3f(o1, o2, v[g]);
+          m1[g] = lt1 ? v[g] : o1;
+          b2[g] = lt1 ? ob1 : t2;
+          b1[g] = lt1 ? sb : ob1;
+        }
+      }
+    } else {
+  #pragma unroll 1
+      for (int h = 0; h < kTileSB; ++h) {
+        const int sb = tl * kTileSB + h;
+        float v[kQG];
+  #pragma unroll
+        for (int g = 0; g < kQG; ++g) v[g] = INFINITY;
+  #pragma unroll 1
+        for (int blk = 0; blk < kSBB; blk += 2) {   // not unrolled: unrolled, hipcc hoists all the MFMAs and spills their results
+          // Two blocks x two query groups = eight MFMAs issued back to back: the four that start an accumulation, then
+          // the four that finish one (each 128 cycles behind the MFMA it depends on).  Left to itself hipcc reuses ONE
+          // result register block and serialises MFMA -> MFMA -> 8 dependent v_min3 (matrix pipe 57 % busy).
+          const uint4* t0 = &tile[cur][(h * kSBB + blk) * kEntB];
+          const uint4* t1 = t0 + kEntB;
+          const bf16x8 a10 = __builtin_bit_cast(bf16x8, t0[lane]);           // k-groups 0 | 1
+          const bf16x8 a20 = __builtin_bit_cast(bf16x8, t0[64 + col]);       // k-group 2 for both halves: the upper half
+          const bf16x8 a11 = __builtin_bit_cast(bf16x8, t1[lane]);           //   meets zeros in bq2
+          const bf16x8 a21 = __builtin_bit_cast(bf16x8, t1[64 + col]);
+          f32x16 r[2][kQG];
+  #pragma unroll
+          for (int g = 0; g < kQG; ++g) {
+            r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a10, bq1[g], zero16, 0, 0, 0);
+            r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a11, bq1[g], zero16, 0, 0, 0);
+          }
+  #pragma unroll
+          for (int g = 0; g < kQG; ++g) {
+            r[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a20, bq2[g], r[0][g], 0, 0, 0);
+            r[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a21, bq2[g], r[1][g], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int g = 0; g < kQG; ++g) {
+            float wa = min3(r[0][g][0], r[0][g][1], r[0][g][2]);
+            float wb = min3(r[1][g][0], r[1][g][1], r[1][g][2]);
+  #pragma unroll
+            for (int i = 3; i < 15; i += 2) {
+              wa = min3(wa, r[0][g][i], r[0][g][i + 1]);
+              wb = min3(wb, r[1][g][i], r[1][g][i + 1]);
+            }
+            v[g] = min3(v[g], wa, wb);
+            v[g] = min3(v[g], r[0][g][15], r[1][g][15]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+  #pragma unroll
+        for (int g = 0; g < kQG; ++g) {
+          // sorted insertion of (v, sb) into the three smallest superblock minima (v_med3 x2, 2 compares, 4 selects)
+          const float o1 = m1[g], o2 = m2[g], o3 = m3[g];
+          const int ob1 = b1[g], ob2 = b2[g];
+          const bool lt1 = v[g] < o1, lt2 = v[g] < o2;
+          const int t2 = lt2 ? sb : ob2;
+          m3[g] = __builtin_amdgcn_fmed3f(o2, o3, v[g]);
+          m2[g] = __builtin_amdgcn_fmed3f(o1, o2, v[g]);
+          m1[g] = lt1 ? v[g] : o1;
+          b2[g] = lt1 ? ob1 : t2;
+          b1[g] = lt1 ? sb : ob1;
+        }
       }
     }
     if (more) {
@@ -510,7 +586,10 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   a.nblocks = (int)(blocks0 + blocks1);
   const long long blocks = blocks0 + blocks1;
   PTOPS_REQUIRE(blocks < (1LL << 31), "chamfer_forward(mfma): grid too large");
-  hipLaunchKernelGGL(chamfer_mfma_kernel, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+  if (ptops::option("PTOPS_CHAMFER_MFMA_NO_PREFETCH"))
+    hipLaunchKernelGGL(chamfer_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+  else
+    hipLaunchKernelGGL(chamfer_mfma_kernel<true>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
   rc = ptops::check_launch("chamfer_mfma_kernel");
   if (rc != PTOPS_OK) return rc;
   for (int d = 0; d < 2; ++d) {

@@ -90,8 +90,11 @@ __device__ __forceinline__ int entry_index(int t) {
 // Thread t < 256 stages A entry t, thread t >= 256 stages B entry t - 256 (one entry = 8 f32 of one row -> 3 x 16 bytes).
 // With 4 waves per tile and 432 tiles (M = 18432, N = 384) a SIMD mostly hosts ONE wave, whose LDS / staging / barrier
 // phases leave the matrix pipe idle; 8 waves put two waves of every tile on each SIMD (107 -> ? TFLOP/s).
+// (512, 3): three workgroups per CU (24 waves; 50.7 KB of LDS each, <= 80 VGPRs) - one more set of waves to fill the
+// LDS / split / barrier phases of the others: +1..4 % over two (benchmarks/probes/gemm_pingpong_probe.hip, round 3; the
+// "ping-pong" role split of the two wave halves measured there is 3-30 % SLOWER than this loop).
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512, 2) void gemm_split3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, 3) void gemm_split3_kernel(GemmArgs g) {
   // [buffer][operand][piece][k-half * kPlane + row]
   __shared__ uint4 lds[2][2][3][2 * kPlane];
 

@@ -219,13 +219,17 @@ class AdaPoinTr(nn.Module):
         through tuned GEMMs without the two transposes (and their copies) of `conv(q.transpose(1,2)).transpose(1,2)`
         (AdaPoinTr.py:222-224 of the reference).  Same parameters, same state-dict keys."""
         conv1, bn, act, conv2 = self.increase_dim
-        if not (TOKEN_MAJOR_INCREASE_DIM and isinstance(conv1, nn.Conv1d) and isinstance(bn, nn.BatchNorm1d)
+        # nn.SyncBatchNorm (main.py --sync_bn -> convert_sync_batchnorm) is not an nn.BatchNorm1d, but it normalises
+        # [rows, C] like one (with the statistics all-reduced over the ranks): the token-major GEMMs stay, only the fused
+        # local-statistics kernel below is skipped for it
+        if not (TOKEN_MAJOR_INCREASE_DIM and isinstance(conv1, nn.Conv1d)
+                and isinstance(bn, (nn.BatchNorm1d, nn.SyncBatchNorm))
                 and conv1.kernel_size == (1,) and conv2.kernel_size == (1,)):
             return self.increase_dim(q.transpose(1, 2)).transpose(1, 2)
         B, M, C = q.shape
         h = _linear_tokens(q.reshape(B * M, C), conv1.weight.squeeze(-1), conv1.bias)
-        if (bn.training and h.is_cuda and h.dtype == torch.float32 and _native.backend_for_testing() is None
-                and bn.affine and bn.track_running_stats and isinstance(act, nn.LeakyReLU) and h.size(1) % 4 == 0):
+        if (isinstance(bn, nn.BatchNorm1d) and bn.training and h.is_cuda and h.dtype == torch.float32
+                and _native.backend_for_testing() is None and bn.affine and bn.track_running_stats and isinstance(act, nn.LeakyReLU) and h.size(1) % 4 == 0):
             h = _BatchNormRowsLeakyReLU.apply(h.contiguous(), bn.weight, bn.bias, bn, act.negative_slope)
         else:
             h = act(bn(h))                                                    # BatchNorm1d accepts [rows, C]

@@ -87,6 +87,18 @@ int ptops_chamfer_backward(const float* xyz1, const float* xyz2,
                            int B, int n, int m,
                            float* grad_xyz1, float* grad_xyz2, void* stream);
 
+/* The same gradients with a FIXED summation order (that of a scalar loop over cloud 1, then cloud 2, each adding its
+ * own term and the negated term of its neighbour) instead of the reference's atomicAdd arrival order (chamfer.cu:193-198):
+ * bit-identical from run to run, no atomics, no zero-fill.  The nearest-neighbour map is transposed once per call in
+ * LDS, hence max(n, m) <= 16384; workspace of ptops_chamfer_backward_det_workspace_bytes(B, n, m) bytes, 16-byte
+ * aligned.  Values agree with ptops_chamfer_backward to the rounding of that reordering. */
+size_t ptops_chamfer_backward_det_workspace_bytes(int B, int n, int m);
+int ptops_chamfer_backward_det(const float* xyz1, const float* xyz2,
+                               const int32_t* idx1, const int32_t* idx2,
+                               const float* grad_dist1, const float* grad_dist2,
+                               int B, int n, int m, float* grad_xyz1, float* grad_xyz2,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------- farthest point sampling --
  * Replaces pointnet2_ops.pointnet2_utils.furthest_point_sample (third-party,
  * un-vendored; call sites models/base_blocks.py:550, utils/misc.py:37).
@@ -298,7 +310,7 @@ size_t ptops_colsum_workspace_bytes(int M, int N);
 int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
 
 /* A/B switches of the library (PTOPS_ATTN_FWD_F32, PTOPS_ATTN_BWD_F32, PTOPS_ATTN_FWD_WAVES, PTOPS_ATTN_DKV_WAVES,
- * PTOPS_ATTN_QSPLIT, PTOPS_GEMM_PINGPONG): each is initialised ONCE from the environment variable of the same name
+ * PTOPS_ATTN_QSPLIT, PTOPS_ATTN_NO_XCD_REMAP, PTOPS_CHAMFER_MFMA_NO_PREFETCH, PTOPS_GEMM_PINGPONG): each is initialised ONCE from the environment variable of the same name
  * and afterwards changes only through ptops_set_option (returns the previous value, -1 for an unknown name), so that
  * a benchmark's label and the kernel that ran agree.  Benchmarking / test aid, not a tuning interface. */
 int ptops_set_option(const char* name, int value);

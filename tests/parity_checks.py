@@ -389,42 +389,66 @@ def check_chamfer_baselines(device, tol=1e-4):
     return report
 
 
+class _ChamferL2F64(torch.nn.Module):
+    """ChamferDistanceL2 by brute force in the dtype of its inputs (the float64 referee of check_baseline_forms)."""
+
+    def forward(self, a, b):
+        d = (a.unsqueeze(2) - b.unsqueeze(1)).pow(2).sum(-1)
+        return d.min(2)[0].mean() + d.min(1)[0].mean()
+
+
 def check_baseline_forms(device):
-    """Token-major / split-first-layer execution vs the literal channel-first form on the same modules:
-    train-mode outputs, running statistics and every parameter gradient (B = 8, small widths)."""
+    """Token-major / split-first-layer execution and the literal channel-first form of the reference, each judged
+    against a FLOAT64 evaluation of the same modules (literal form, brute-force Chamfer): train-mode outputs, running
+    statistics and the whole gradient (B = 8, small widths).
+
+    Why a referee and not form vs form (round-2 review): these networks push 8-cloud batch statistics through up to
+    24 stacked train-mode BatchNorms, and FoldingNet's gradient moves by 2e-4 when its float64 inputs move by one fp32
+    ulp - so BOTH fp32 forms sit ~2e-2 from the float64 gradient (profiles/round3/baseline_forms_referee_v1.log:
+    token-major 2.106e-2, literal 2.099e-2; PCN 9.1e-4 / 8.8e-4; TopNet 2.1e-4 / 2.1e-4) and their mutual distance
+    (1.7e-3 on most boxes, 2e-2 on one: other library GEMM kernels) is a sample of that same rounding cloud, not a
+    property of either form.  What can be asserted tightly is that the token-major form is no further from float64 than
+    the reference's own form is."""
     from imgadapointr_amd.models import build_model_from_cfg, pointwise
     from imgadapointr_amd.utils.config import EasyDict
     from golden_util import synthetic_batch
     partial, gt = synthetic_batch(8, 256, 512, seed=51, structured=True)
     partial, gt = t(partial, device), t(gt, device)
     report = {}
+
+    def run(cfg, token_major, dtype):
+        pointwise.TOKEN_MAJOR = token_major
+        try:
+            model = build_model_from_cfg(EasyDict(cfg))
+            model.load_state_dict(seeded_state_dict(model.state_dict(), "forms/" + cfg['NAME'], std=0.1))
+            model = model.to(device).to(dtype).train()
+            if dtype == torch.float64:
+                model.loss_func = _ChamferL2F64()
+            ret = model(partial.to(dtype))
+            l0, l1 = model.get_loss(ret, gt.to(dtype))
+            (l0 + l1).backward()
+        finally:
+            pointwise.TOKEN_MAJOR = True
+        return (ret[1].detach().double(), {n: p.grad.double() for n, p in model.named_parameters()},
+                {n: b.double() for n, b in model.named_buffers() if b.is_floating_point()})
+
+    def grad_err(g, ref):
+        return (sum(float((g[n] - ref[n]).pow(2).sum()) for n in ref) / sum(float(ref[n].pow(2).sum()) for n in ref)) ** 0.5
+
     for cfg in (dict(NAME='PCN', num_pred=1024, encoder_channel=1024),
                 dict(NAME='FoldingNet', num_pred=1024, encoder_channel=256),
                 dict(NAME='TopNet', node_feature=8, num_pred=2048, encoder_channel=248, nlevels=6)):
-        runs = []
-        for flag in (True, False):
-            pointwise.TOKEN_MAJOR = flag
-            try:
-                model = build_model_from_cfg(EasyDict(cfg))
-                model.load_state_dict(seeded_state_dict(model.state_dict(), "forms/" + cfg['NAME'], std=0.1))
-                model = model.to(device).train()
-                ret = model(partial)
-                l0, l1 = model.get_loss(ret, gt)
-                (l0 + l1).backward()
-            finally:
-                pointwise.TOKEN_MAJOR = True
-            runs.append((ret[1].detach(), {n: p.grad for n, p in model.named_parameters()},
-                         {n: b for n, b in model.named_buffers() if b.is_floating_point()}))
-        (o1, g1, b1), (o2, g2, b2) = runs
-        d_out = float((o1 - o2).abs().max() / o2.abs().max())
-        gnorm = sum(float(g2[n].double().pow(2).sum()) for n in g2) ** 0.5
-        d_grad = sum(float((g1[n] - g2[n]).double().pow(2).sum()) for n in g2) ** 0.5 / gnorm
-        d_buf = max(float((b1[n] - b2[n]).abs().max() / (1 + b2[n].abs().max())) for n in b2)
-        report[cfg['NAME']] = (d_out, d_grad, d_buf)
-        # The two forms run different GEMM shapes through stacked train-mode BatchNorms over 8 clouds, which amplifies
-        # rounding: the gradient difference measured 1.7e-3 on most boxes and 2.0e-2 on one (other library kernels
-        # picked for the small shapes), outputs 9e-5 .. 1.1e-4; a logic error moves both by O(1).
-        assert d_out < 5e-4 and d_grad < 5e-2 and d_buf < 1e-5, report
+        o64, g64, b64 = run(cfg, False, torch.float64)
+        (o1, g1, b1), (o2, g2, b2) = run(cfg, True, torch.float32), run(cfg, False, torch.float32)
+        scale = float(o64.abs().max())
+        e_out = (float((o1 - o64).abs().max()) / scale, float((o2 - o64).abs().max()) / scale)
+        e_grad = (grad_err(g1, g64), grad_err(g2, g64))
+        e_buf = max(float((b1[n] - b64[n]).abs().max() / (1 + b64[n].abs().max())) for n in b64)
+        report[cfg['NAME']] = dict(out_vs_f64=e_out, grad_vs_f64=e_grad, buf_vs_f64=e_buf, grad_form_vs_form=grad_err(g1, g2))
+        # the token-major form is as close to float64 as the literal form (1.5x: two samples of one rounding cloud), and
+        # neither is further than the worst conditioning measured (FoldingNet, 2.1e-2) allows
+        assert e_out[0] <= 1.5 * e_out[1] + 1e-6 and e_grad[0] <= 1.5 * e_grad[1] + 1e-6, report
+        assert max(e_out) < 5e-4 and max(e_grad) < 6e-2 and e_buf < 1e-5, report
     return report
 
 
@@ -513,10 +537,17 @@ def check_trainstep(case, device):
     assert not any(n in grads for n, p in named.items() if not p.requires_grad)
     gsq = {n: float((v.double() ** 2).sum()) for n, v in grads.items()}
     total, want_total = sum(gsq.values()), float(g["grad_sq_norm_total"])
-    # same resolution as the AdaPoinTr gradient check above: arg-max flips at rounding-level near-ties
-    assert abs(total - want_total) <= 5e-3 * want_total, (total, want_total)
+    # Resolution of the gradient comparison = what rounding alone does to this fixture, measured by running the step
+    # with the GEMM / attention / edge-conv kernels exchanged for the library's and the literal forms
+    # (benchmarks/trainstep_spread.py -> profiles/round3/trainstep_spread_v1.log).  img / segenc: arms agree to 4e-3 in
+    # the gradient vector and 1.4e-3 in |g|^2 - the AdaPoinTr resolution (arg-max flips at near-ties).  seg: the arms
+    # differ from EACH OTHER by 2-5 % in the vector and 0.5 % in |g|^2 (GDANet in train mode over B = 2: feature-space
+    # top-k, top-M sharp/gentle selection and a hard distance mask after the predicted coarse cloud), so that is all this
+    # fixture can resolve; outputs and losses above stay at 3e-4 / 1e-3.
+    tol_total, tol_vec = (1.5e-2, 8e-2) if case == "seg" else (5e-3, 3e-2)
+    assert abs(total - want_total) <= tol_total * want_total, (total, want_total)
     d_norm = max(abs(gsq[n] - v) / max(v, 1e-12) for n, v in mt["grad_sq_norm_sample"].items() if v > 1e-9 * want_total)
-    assert d_norm < 3e-2, d_norm
+    assert d_norm < tol_vec, d_norm
     d_vec = {}
     for key in g.files:
         if key.startswith("grad/"):
@@ -529,8 +560,8 @@ def check_trainstep(case, device):
                 assert np.linalg.norm(got) < 1e-3 * np.sqrt(want_total), n
                 continue
             d_vec[n] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
-    assert len(d_vec) >= 12 and max(d_vec.values()) < 3e-2, d_vec
-    assert abs(float(np.sqrt(total)) - float(g["grad_norm_before_clip"])) < 3e-3 * float(g["grad_norm_before_clip"])
+    assert len(d_vec) >= 12 and max(d_vec.values()) < tol_vec, d_vec
+    assert abs(float(np.sqrt(total)) - float(g["grad_norm_before_clip"])) < tol_total * float(g["grad_norm_before_clip"])
     # after the update: AdamW's first step moves every element by ~lr * sign(g) (lr 1e-4), so an element whose gradient
     # is at rounding level may land 2e-4 away; everything else must agree to a small fraction of one step
     lr = float(cfg.optimizer.kwargs.lr)
@@ -549,7 +580,7 @@ def check_trainstep(case, device):
         moved = max(moved, float(np.abs(got - was).max()))
     # a gradient vector that agrees to 1-2 % (arg-max flips, above) has about that share of elements near zero whose
     # sign, and with it the whole first step, may differ
-    assert far <= 0.06 * n_el, (far, n_el)
+    assert far <= (0.12 if case == "seg" else 0.06) * n_el, (far, n_el)
     assert 0.5 * lr < moved < 1.5 * lr, moved
     d_rm = None
     if "seg_first_running_mean" in g.files:
@@ -576,11 +607,15 @@ def check_multi_view(device, views=3):
     with torch.no_grad():
         coarse, fine = model(partial, imgs)
         assert coarse.shape == (B * views, 512, 3) and fine.shape == (B * views, 16384, 3)
-        d = 0.0
+        d, swapped = 0.0, 0
         for v in range(views):
             c1, f1 = model(partial, imgs[:, v].contiguous())
-            d = max(d, float((coarse[v::views] - c1).abs().max()), float((fine[v::views] - f1).abs().max()))
-    assert d < 2e-5, d
+            # the 512 queries are the top-ranked of 768 proposals: two scores closer than fp32 rounding may swap places
+            # between a batch of B*V and a batch of B (other GEMM kernels), so rows are matched before comparing
+            dc, df, sw = compare_ranked(coarse[v::views].cpu().numpy(), fine[v::views, :2048].cpu().numpy(),
+                                        c1.cpu().numpy(), f1[:, :2048].cpu().numpy(), 2e-5)
+            d, swapped = max(d, dc, df), swapped + sw
+    assert d < 2e-5 and swapped <= 8, (d, swapped)
     # train mode: losses and the gradient that reaches the shared point branch
     model.train()
     for m in model.modules():
@@ -602,5 +637,8 @@ def check_multi_view(device, views=3):
         acc[1] += b.item() / views
     d_loss = (abs(l_den.item() - acc[0]), abs(l_rec.item() - acc[1]))
     d_grad = float((g_folded - w.grad).norm() / w.grad.norm())
-    assert max(d_loss) < 2e-6 and d_grad < 2e-3, (d_loss, d_grad)
+    # CPU: identical arithmetic in both forms.  GPU: a batch of B*V rows runs other GEMM kernels than a batch of B, so
+    # rounding differs (and with it the odd arg-max / rank decision): losses to 5e-5, the shared branch's gradient to 3 %
+    on_cpu = str(device) == "cpu"
+    assert max(d_loss) < (2e-6 if on_cpu else 5e-5) and d_grad < (2e-3 if on_cpu else 3e-2), (d_loss, d_grad)
     return d, d_loss, d_grad

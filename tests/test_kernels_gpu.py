@@ -160,11 +160,44 @@ def test_chamfer_backward(native, ref, B, n, m, kind):
     _, _, j1, j2 = ref.chamfer_forward(a, b)
     g1 = rng.standard_normal((B, n)).astype(np.float32)
     g2 = rng.standard_normal((B, m)).astype(np.float32)
-    ga, gb = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2))
     ra, rb = ref.chamfer_backward(a, b, j1, j2, g1, g2)
-    # atomics sum in a different order than the oracle's loops: a few ulps of the largest term
+    # the reference's form (chamfer.cu:193-198): atomics sum in arrival order, a few ulps of the largest term
+    ga, gb = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=False)
     np.testing.assert_allclose(ga.cpu().numpy(), ra, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(gb.cpu().numpy(), rb, rtol=1e-5, atol=1e-5)
+    # the deterministic form sums in the order of the oracle's scalar loops: bit-exact, and the same on every run
+    da, db = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=True)
+    assert np.array_equal(da.cpu().numpy().view(np.uint32), ra.view(np.uint32))
+    assert np.array_equal(db.cpu().numpy().view(np.uint32), rb.view(np.uint32))
+    for _ in range(3):
+        ea, eb = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=True)
+        assert torch.equal(ea, da) and torch.equal(eb, db)
+
+
+def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
+    """Rows of every length: a prediction collapsed onto a few target points sends thousands of points to one
+    neighbour (the long-row paths of the transposition and of the summation), mixed with isolated points and points
+    nobody chose; a full-size call (B = 4, 16384 x 16384) for the LDS limits."""
+    rng = np.random.default_rng(99)
+    for B, n, m, centres in ((2, 5000, 3000, 3), (1, 16384, 16384, 40), (4, 16384, 16384, 0), (2, 70, 16384, 1)):
+        b = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+        if centres:
+            pick = rng.integers(0, m, (B, centres))
+            a = np.stack([b[i][pick[i][rng.integers(0, centres, n)]] for i in range(B)]) + \
+                rng.standard_normal((B, n, 3)).astype(np.float32) * 1e-3
+            a[:, : n // 10] = rng.random((B, n // 10, 3), dtype=np.float32) - 0.5
+        else:
+            a = rng.random((B, n, 3), dtype=np.float32) - 0.5
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        _, _, j1, j2 = ref.chamfer_forward(a, b)
+        if centres:
+            assert np.bincount(j1[0], minlength=m).max() > 64          # the long-row path is really taken
+        g1 = rng.standard_normal((B, n)).astype(np.float32)
+        g2 = rng.standard_normal((B, m)).astype(np.float32)
+        ra, rb = ref.chamfer_backward(a, b, j1, j2, g1, g2)
+        da, db = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=True)
+        assert np.array_equal(da.cpu().numpy().view(np.uint32), ra.view(np.uint32)), (B, n, m)
+        assert np.array_equal(db.cpu().numpy().view(np.uint32), rb.view(np.uint32)), (B, n, m)
 
 
 FPS_CASES = [(2, 2048, 512, "uniform"), (3, 512, 256, "uniform"), (2, 2048, 256, "shell"), (2, 2048, 64, "shell"),
@@ -605,19 +638,47 @@ def test_fused_edge_conv_matches_literal_chain(native, B, N):
         res[fused] = (coor.detach(), f.detach(), [t.detach() for t in grads])
     BB.FUSED_EDGE_CONV = True
     assert torch.equal(res[True][0], res[False][0])
-    fa, fb = res[True][1], res[False][1]
-    assert (fa - fb).abs().max().item() < 2e-5 * max(1.0, fb.abs().max().item())
-    for (name, _), a, b in zip([("x", None)] + list(g.named_parameters()), res[True][2], res[False][2]):
-        # A near-tie between two neighbours (top-2 gap below the fp32 rounding of P+R vs the concatenated
-        # convolution) may select the other edge; that moves one O(1) contribution of this loss to another
-        # source point and fans out through the earlier stages (benchmarks/edgeconv_referee.py shows the
-        # same effect between the literal fp32 and float64 chains).  Strict at N=512 (no such near-tie for
-        # this seed), relative L2 at N=2048.
-        # (which near-ties exist depends on the rounding of the BLAS kernels the library picks on the box at hand, so
-        #  both sizes use the flip-tolerant relative L2 metric; the element-wise check against float64 on identical
-        #  inputs is test_fused_edge_conv_function_vs_float64)
-        rel = ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
-        assert rel < 2e-2, (name, rel)
+
+    # the referee: the literal chain of the same grouper in float64 (kNN / FPS picks from the fp32 kernels, so all three
+    # evaluations see the same graph), as in benchmarks/edgeconv_referee.py
+    from imgadapointr_amd.models.Transformer_utils import knn_idx
+
+    class G64(BB.DGCNN_Grouper):
+        def edge_conv(self, layer, coor_q, x_q, coor_k, x_k):
+            idx = knn_idx(self.k, coor_k.float().transpose(-1, -2).contiguous(),
+                          coor_q.float().transpose(-1, -2).contiguous()).long()
+            Bq, C, Nk = x_k.shape
+            Nq = x_q.shape[2]
+            nb = torch.gather(x_k.unsqueeze(2).expand(Bq, C, Nq, Nk), 3, idx.unsqueeze(1).expand(Bq, C, Nq, self.k))
+            feat = torch.cat([nb - x_q.unsqueeze(-1), x_q.unsqueeze(-1).expand_as(nb)], dim=1)
+            return layer(feat).max(dim=-1)[0]
+
+        @staticmethod
+        def fps_downsample(coor, x, num_group, fps_idx=None):
+            idx = native.furthest_point_sample(coor.float().transpose(1, 2).contiguous(), num_group).long()
+            comb = torch.cat([coor, x], dim=1)
+            out = torch.gather(comb, 2, idx.unsqueeze(1).expand(-1, comb.size(1), -1))
+            return out[:, :3], out[:, 3:]
+
+    g64 = G64(k=16)
+    g64.load_state_dict(sd)
+    g64 = g64.cuda().double()
+    xin = x.double().clone().requires_grad_(True)
+    _, f64 = g64(xin, [N // 4, N // 8])
+    w64 = torch.linspace(-1, 1, f64.numel(), device="cuda").view_as(f64).double()
+    ref = [t.detach() for t in torch.autograd.grad((f64 * w64).sum(), [xin] + list(g64.parameters()))]
+
+    fa, fb = res[True][1].double(), res[False][1].double()
+    scale = max(1.0, f64.abs().max().item())
+    assert (fa - f64).abs().max().item() < 2e-5 * scale and (fb - f64).abs().max().item() < 2e-5 * scale
+    for (name, _), a, b, r in zip([("x", None)] + list(g.named_parameters()), res[True][2], res[False][2], ref):
+        # A near-tie between two neighbours (top-2 gap below fp32 rounding) may select the other edge in ANY fp32
+        # evaluation, fused or literal; that moves one O(1) contribution of this loss to another source point and fans
+        # out through the earlier stages.  Each form is therefore judged against float64 (relative L2, flip-tolerant):
+        # the fused kernels must be as close to it as the reference's literal chain is.
+        ea = ((a.double() - r).norm() / r.norm().clamp_min(1e-12)).item()
+        eb = ((b.double() - r).norm() / r.norm().clamp_min(1e-12)).item()
+        assert ea <= 1.5 * eb + 1e-5 and max(ea, eb) < 2e-2, (name, ea, eb)
 
 
 @pytest.mark.parametrize("B,C,Nq,Nk,k,G", [(2, 32, 300, 700, 16, 4), (3, 64, 512, 512, 8, 4), (1, 128, 256, 512, 16, 4)])

@@ -132,3 +132,37 @@ def test_full_train_step_of_the_fused_families_matches_reference(case):
 
 def test_multi_view_batch_equals_separate_views():
     print(pc.check_multi_view("cpu", views=2))
+
+
+def test_sync_bn_conversion_keeps_the_token_major_head():
+    """`--sync_bn` (tools/runner.py:85-87 of the reference: nn.SyncBatchNorm.convert_sync_batchnorm before the DDP wrap)
+    turns the one BatchNorm1d of AdaPoinTr.increase_dim into a SyncBatchNorm.  The head must keep its token-major GEMM
+    form (no [B,C,M] transposes) with that module doing the normalisation: same outputs as the unconverted model in
+    train and eval mode, same state-dict keys.  (The all-reduce of the statistics itself needs GPUs: SyncBatchNorm has no
+    CPU / gloo implementation; a single process falls back to local statistics, which is what is compared here.)"""
+    from imgadapointr_amd.models import AdaPoinTr as A
+    model, _ = pc.build_adapointr("cpu")
+    keys = list(model.state_dict())
+    torch.manual_seed(0)
+    q = torch.randn(2, 576, 384)
+    model.train()
+    want_train = model._increase_dim(q)
+    rm = model.increase_dim[1].running_mean.clone()
+    model.eval()
+    want_eval = model._increase_dim(q)
+    model2, _ = pc.build_adapointr("cpu")
+    model2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model2)
+    assert isinstance(model2.increase_dim[1], torch.nn.SyncBatchNorm) and list(model2.state_dict()) == keys
+    calls = []
+    orig = A._linear_tokens
+    A._linear_tokens = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        model2.train()
+        got_train = model2._increase_dim(q)
+        model2.eval()
+        got_eval = model2._increase_dim(q)
+    finally:
+        A._linear_tokens = orig
+    assert len(calls) == 4                                   # two token-major GEMMs per call: not the literal Conv1d path
+    assert torch.allclose(got_train, want_train, atol=1e-5) and torch.allclose(got_eval, want_eval, atol=1e-5)
+    assert torch.allclose(model2.increase_dim[1].running_mean, rm, atol=1e-6)

@@ -143,3 +143,75 @@ def test_flat_ddp_call_sequence_on_rccl(native):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank.py")], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and "rccl single-rank ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_fast_paths_single_step_all_gradients(native):
+    """ONE production train step of AdaPoinTr at the bench configuration (bs = 32, where every fast path is active:
+    split-bf16 GEMMs incl. weight gradients and Linear + GELU, split-bf16 attention forward / backward, deferred folds,
+    fused clip + AdamW) against the same step with all of them switched off (library GEMMs, f32-MFMA attention, immediate
+    folds, clip_grad_norm_ + AdamW.step): both losses, EVERY parameter gradient tensor by tensor, and every parameter
+    after the update.  A 30-step loss trajectory cannot tell a small systematic error in one kernel from chaotic drift
+    (round-2 review); the first step can."""
+    import parity_checks as pc
+    from imgadapointr_amd.models import Transformer_utils as TU
+    from imgadapointr_amd.tools import builder, runner
+    from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm
+    enable_tuned_gemm()
+    B = 32
+    torch.manual_seed(0)
+    partial = (torch.rand(B, 2048, 3) - 0.5).cuda()
+    gt = (torch.rand(B, 16384, 3) - 0.5).cuda()
+    noise = (torch.randn(B, 64, 3) * 0.01).clamp_(-0.05, 0.05).cuda()
+    saved = (TU.USE_SPLIT3_GEMM, TU.USE_SPLIT3_WGRAD, TU.FUSED_LINEAR_GELU, TU.USE_MFMA_ATTENTION_BWD, runner.DEFER_FOLDS,
+             runner.FUSED_CLIP_ADAMW)
+
+    def run(fast):
+        (TU.USE_SPLIT3_GEMM, TU.USE_SPLIT3_WGRAD, TU.FUSED_LINEAR_GELU, TU.USE_MFMA_ATTENTION_BWD, runner.DEFER_FOLDS,
+         runner.FUSED_CLIP_ADAMW) = saved if fast else (False, False, False, "fused", False, False)
+        native.set_option("PTOPS_ATTN_FWD_F32", 0 if fast else 1)
+        model, cfg = pc.build_adapointr("cuda")
+        model.train()
+        named = dict(model.named_parameters())
+        step = runner.TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
+        grads = {}
+        step.before_update = lambda: grads.update({n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None})
+        before = {n: p.detach().clone() for n, p in named.items()}
+        l0, l1 = step(partial, gt, (), 0, denoise_noise=noise)
+        return (l0.item(), l1.item()), grads, before, {n: p.detach().clone() for n, p in named.items()}
+
+    try:
+        (fa, ga, _, pa), (fb, gb, before, pb) = run(True), run(False)
+    finally:
+        (TU.USE_SPLIT3_GEMM, TU.USE_SPLIT3_WGRAD, TU.FUSED_LINEAR_GELU, TU.USE_MFMA_ATTENTION_BWD, runner.DEFER_FOLDS,
+         runner.FUSED_CLIP_ADAMW) = saved
+        native.set_option("PTOPS_ATTN_FWD_F32", 0)
+    assert abs(fa[0] - fb[0]) < 2e-5 * abs(fb[0]) and abs(fa[1] - fb[1]) < 2e-5 * abs(fb[1]), (fa, fb)
+    assert set(ga) == set(gb) and len(ga) == 335 - 8
+    total = sum(float(v.double().pow(2).sum()) for v in gb.values()) ** 0.5
+    worst, n_checked = ("", 0.0), 0
+    for n in gb:
+        ref_norm = float(gb[n].double().norm())
+        err = float((ga[n].double() - gb[n].double()).norm())
+        if ref_norm < 1e-5 * total:                     # gradients that are zero in exact arithmetic (k_map biases ...)
+            assert float(ga[n].double().norm()) < 1e-4 * total, n
+            continue
+        n_checked += 1
+        if err / ref_norm > worst[1]:
+            worst = (n, err / ref_norm)
+    # rounding-level differences flip a few arg-maxes (max-pools, kNN-free top-k of the query ranking), which moves single
+    # tensors by up to ~1 % (tests/parity_checks.py); a wrong kernel moves its tensor by O(1)
+    assert n_checked >= 300 and worst[1] < 2e-2, worst
+    lr = 1e-4
+    far = n_el = 0
+    for n in pb:
+        if n not in gb:
+            assert torch.equal(pa[n], before[n]) and torch.equal(pb[n], before[n]), n       # no gradient: untouched
+            continue
+        d = (pa[n] - pb[n]).abs()
+        far += int((d > 0.05 * lr).sum())
+        n_el += d.numel()
+        assert float(d.max()) <= 2.2 * lr, (n, float(d.max()))
+    assert far <= 0.03 * n_el, (far, n_el)              # first AdamW step = lr * sign(g): only near-zero gradients differ
+    print("worst gradient tensor", worst, "elements off after the update", far / n_el)
