@@ -31,17 +31,17 @@ def main():
     for name, (a, b) in cases.items():
         res = {}
         for mode in (0, 1):
-            nat.set_option("PTOPS_CHAMFER_MFMA_NO_PREFETCH", mode)
+            nat.set_option("PTOPS_CHAMFER_MFMA_PREFETCH", mode)
             res[mode] = nat.chamfer_forward(a, b, algorithm=nat.CHAMFER_MFMA)
         assert all(torch.equal(u, v) for u, v in zip(res[0], res[1]))
         t = {0: [], 1: []}
         for _ in range(7):
             for mode in (1, 0):
-                nat.set_option("PTOPS_CHAMFER_MFMA_NO_PREFETCH", mode)
+                nat.set_option("PTOPS_CHAMFER_MFMA_PREFETCH", mode)
                 t[mode].append(timed(lambda: nat.chamfer_forward(a, b, algorithm=nat.CHAMFER_MFMA)))
         med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
-        print(f"{name:22s} without prefetch {med[1]:8.1f} us   with prefetch {med[0]:8.1f} us   (prep + search, median of 7 x 5)", flush=True)
-    nat.set_option("PTOPS_CHAMFER_MFMA_NO_PREFETCH", 0)
+        print(f"{name:22s} with prefetch {med[1]:8.1f} us   without prefetch {med[0]:8.1f} us   (prep + search, median of 7 x 5)", flush=True)
+    nat.set_option("PTOPS_CHAMFER_MFMA_PREFETCH", 0)
 
 
 if __name__ == "__main__":

@@ -586,10 +586,13 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   a.nblocks = (int)(blocks0 + blocks1);
   const long long blocks = blocks0 + blocks1;
   PTOPS_REQUIRE(blocks < (1LL << 31), "chamfer_forward(mfma): grid too large");
-  if (ptops::option("PTOPS_CHAMFER_MFMA_NO_PREFETCH"))
-    hipLaunchKernelGGL(chamfer_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
-  else
+  // PTOPS_CHAMFER_MFMA_PREFETCH=1: the fragment-prefetch variant of the inner loop.  Measured SLOWER (B = 32, 16384^2:
+  // 1.62 vs 0.94 ms, profiles/round3/chamfer_mfma_ab_v1.log): the second fragment set does not fit the 128 registers
+  // of four workgroups per CU and hipcc spills inside the loop; kept switchable for the record.
+  if (ptops::option("PTOPS_CHAMFER_MFMA_PREFETCH"))
     hipLaunchKernelGGL(chamfer_mfma_kernel<true>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+  else
+    hipLaunchKernelGGL(chamfer_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
   rc = ptops::check_launch("chamfer_mfma_kernel");
   if (rc != PTOPS_OK) return rc;
   for (int d = 0; d < 2; ++d) {

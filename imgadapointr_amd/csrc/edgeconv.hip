@@ -371,43 +371,43 @@ __global__ __launch_bounds__(kCsrT) void edge_csr_kernel(const int32_t* __restri
 }
 
 // dP[c, n] = cnt[n] (A + Bc P[c, n]) + Bc sum_{q in row n} R[c, q] + sum_{q : nsel[c, q] = n} S[c, q]
-// The dense term is a gather over the transposed graph from an LDS copy of Bc R[c, :]; only the selected-edge term
-// (one value per (channel, query) instead of k + 1) still goes through LDS float atomics.
+// Both sums are gathers over the transposed graph from LDS copies of the per-query values: the selected source of a
+// query is one of its k (distinct) neighbours, so every q with nsel[c, q] = n is in row n.  No atomics: the summation
+// order is the row order (ascending q) and dP is bit-identical from run to run (round 3; the selected-edge term used
+// to go through LDS float atomics).
 template <int CT>
 __global__ __launch_bounds__(kTPB) void edge_gather_dp_kernel(
     const float* __restrict__ P, const float* __restrict__ R, const float* __restrict__ S,
     const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ col, const int32_t* __restrict__ nsel,
     const float* __restrict__ ab, int C, int G, int Nk, int Nq, int k, float* __restrict__ dP) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // rt[CT][Nq] | at[CT][Nk]
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // rt[CT][Nq] | st[CT][Nq] | sn[CT][Nq] (uint16)
   float* rt = tile;
-  float* at = tile + (size_t)CT * Nq;
+  float* st = tile + (size_t)CT * Nq;
+  uint16_t* sn = reinterpret_cast<uint16_t*>(st + (size_t)CT * Nq);
   const int b = blockIdx.y, c0 = blockIdx.x * CT;
   const int cpg = C / G;
   for (int t = threadIdx.x; t < CT * Nq; t += kTPB) {
     const int ct = t / Nq, q = t - ct * Nq, c = c0 + ct;
-    rt[t] = c < C ? ab[2 * (b * G + c / cpg) + 1] * R[((size_t)b * C + c) * Nq + q] : 0.0f;
-  }
-  for (int t = threadIdx.x; t < CT * Nk; t += kTPB) at[t] = 0.0f;
-  __syncthreads();
-  for (int t = threadIdx.x; t < CT * Nq; t += kTPB) {
-    const int ct = t / Nq, q = t - ct * Nq, c = c0 + ct;
-    if (c < C) {
-      const size_t o = ((size_t)b * C + c) * Nq + q;
-      atomicAdd(&at[ct * Nk + nsel[o]], S[o]);
-    }
+    const size_t o = ((size_t)b * C + c) * Nq + q;
+    rt[t] = c < C ? ab[2 * (b * G + c / cpg) + 1] * R[o] : 0.0f;
+    st[t] = c < C ? S[o] : 0.0f;
+    sn[t] = c < C ? (uint16_t)nsel[o] : (uint16_t)0xFFFF;
   }
   __syncthreads();
   const int32_t* rp = rowptr + (size_t)b * (Nk + 1);
   const uint16_t* gc = col + (size_t)b * Nq * k;
   for (int n = threadIdx.x; n < Nk; n += kTPB) {
     const int beg = rp[n], end = rp[n + 1];
-    float acc[CT];
+    float acc[CT], sel[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[ct] = 0.0f;
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = 0.0f, sel[ct] = 0.0f;
     for (int e = beg; e < end; ++e) {
       const int q = gc[e];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[ct] += rt[ct * Nq + q];
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[ct] += rt[ct * Nq + q];
+        sel[ct] += sn[ct * Nq + q] == (uint16_t)n ? st[ct * Nq + q] : 0.0f;
+      }
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kTPB) void edge_gather_dp_kernel(
       if (c < C) {
         const float A = ab[2 * (b * G + c / cpg)], Bc = ab[2 * (b * G + c / cpg) + 1];
         const size_t o = ((size_t)b * C + c) * Nk + n;
-        dP[o] = (at[ct * Nk + n] + acc[ct]) + (float)(end - beg) * (A + Bc * P[o]);
+        dP[o] = (sel[ct] + acc[ct]) + (float)(end - beg) * (A + Bc * P[o]);
       }
     }
   }
@@ -423,8 +423,10 @@ __global__ __launch_bounds__(kTPB) void edge_gather_dp_kernel(
 
 // LDS bytes of the two kernels; the CSR path is used when both fit (else the atomic scatter above)
 size_t csr_lds_bytes(int Nk, int Nq, int k) { return sizeof(int) * (2 * (size_t)Nk + kCsrT) + sizeof(uint16_t) * (size_t)Nq * k + 16; }
+// bytes of LDS per channel of edge_gather_dp_kernel: two floats and one uint16 per query
+inline size_t dp_lds_per_channel(int Nq) { return (2 * sizeof(float) + sizeof(uint16_t)) * (size_t)Nq; }
 bool csr_eligible(int Nk, int Nq, int k) {
-  return Nq <= 65535 && csr_lds_bytes(Nk, Nq, k) <= 150 * 1024 && sizeof(float) * ((size_t)Nq + Nk) <= 64 * 1024;
+  return Nq <= 65535 && Nk <= 65535 && csr_lds_bytes(Nk, Nq, k) <= 150 * 1024 && dp_lds_per_channel(Nq) <= 96 * 1024;
 }
 size_t csr_workspace_bytes(int B, int Nk, int Nq, int k) {
   const size_t rowptr = (sizeof(int32_t) * (size_t)B * (Nk + 1) + 15) / 16 * 16;
@@ -527,9 +529,13 @@ PTOPS_API int ptops_edge_norm_backward(const float* grad_out, const float* ysel,
                               (int)csr_lds);
     hipLaunchKernelGGL(edge_csr_kernel, dim3(B), dim3(kCsrT), csr_lds, stream, idx, Nk, Nq, k, rowptr, col);
     int CT = 8;
-    while (CT > 1 && ((long long)B * ptops::ceil_div(C, CT) < 512 || (size_t)CT * (Nq + Nk) * 4 > 64 * 1024)) CT >>= 1;
+    while (CT > 1 && ((long long)B * ptops::ceil_div(C, CT) < 512 || CT * dp_lds_per_channel(Nq) > 96 * 1024)) CT >>= 1;
     dim3 grid(ptops::ceil_div(C, CT), B);
-    const size_t lds = (size_t)CT * ((size_t)Nq + Nk) * sizeof(float);
+    const size_t lds = (CT * dp_lds_per_channel(Nq) + 15) / 16 * 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_gather_dp_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_gather_dp_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_gather_dp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_gather_dp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     switch (CT) {
       case 8: hipLaunchKernelGGL(edge_gather_dp_kernel<8>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;
       case 4: hipLaunchKernelGGL(edge_gather_dp_kernel<4>, grid, dim3(kTPB), lds, stream, P, R, S, rowptr, col, nsel, ab, C, groups, Nk, Nq, k, dP); break;

@@ -93,8 +93,8 @@ __device__ __forceinline__ int entry_index(int t) {
 // (512, 3): three workgroups per CU (24 waves; 50.7 KB of LDS each, <= 80 VGPRs) - one more set of waves to fill the
 // LDS / split / barrier phases of the others: +1..4 % over two (benchmarks/probes/gemm_pingpong_probe.hip, round 3; the
 // "ping-pong" role split of the two wave halves measured there is 3-30 % SLOWER than this loop).
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512, 3) void gemm_split3_kernel(GemmArgs g) {
+template <bool AKC, bool BKC, int OCC = 3>
+__global__ __launch_bounds__(512, OCC) void gemm_split3_kernel(GemmArgs g) {
   // [buffer][operand][piece][k-half * kPlane + row]
   __shared__ uint4 lds[2][2][3][2 * kPlane];
 
@@ -332,7 +332,10 @@ static int gemm_split3_launch(const float* A, long long lda, int a_k_contiguous,
   const long long blocks = (long long)ptops::ceil_div(M, kBM) * g.tiles_n;
   PTOPS_REQUIRE(blocks < (1LL << 31), "gemm_f32_split3: grid too large");
   dim3 grid((unsigned)blocks), block(512);
-  if (a_k_contiguous && b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, block, 0, stream, g);
+  if (a_k_contiguous && b_k_contiguous) {
+    if (ptops::option("PTOPS_GEMM_OCC2")) hipLaunchKernelGGL((gemm_split3_kernel<true, true, 2>), grid, block, 0, stream, g);   // A/B
+    else hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, block, 0, stream, g);
+  }
   else if (a_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, block, 0, stream, g);
   else if (b_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((gemm_split3_kernel<false, false>), grid, block, 0, stream, g);

@@ -190,7 +190,7 @@ def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
             a = rng.random((B, n, 3), dtype=np.float32) - 0.5
         a = np.ascontiguousarray(a, dtype=np.float32)
         _, _, j1, j2 = ref.chamfer_forward(a, b)
-        if centres:
+        if centres and n > 1000:
             assert np.bincount(j1[0], minlength=m).max() > 64          # the long-row path is really taken
         g1 = rng.standard_normal((B, n)).astype(np.float32)
         g2 = rng.standard_normal((B, m)).astype(np.float32)
