@@ -39,7 +39,7 @@ def main():
 
     arms = [("shipped defaults", (lambda: None, lambda: None)),
             ("Chamfer backward with atomics (reference form)", attr(_native, "DETERMINISTIC_BACKWARD", False)),
-            ("forward GEMM at two workgroups per CU", opt("PTOPS_GEMM_OCC2", 1)),
+            ("forward GEMM at three workgroups per CU", opt("PTOPS_GEMM_OCC3", 1)),
             ("attention without the XCD job order", opt("PTOPS_ATTN_NO_XCD_REMAP", 1)),
             ("immediate folds", attr(runner, "DEFER_FOLDS", False)),
             ("Chamfer MFMA with fragment prefetch", opt("PTOPS_CHAMFER_MFMA_PREFETCH", 1))]

@@ -238,13 +238,16 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 // ---- deterministic backward (round 3): the neighbour half without float atomics ------------------------------------
 // The reference (chamfer.cu:193-198) and chamfer_grad_kernel<true> add the neighbour terms with atomicAdd, i.e. in
 // arrival order: gradients differ in the last bits from run to run.  Here the nearest-neighbour map is transposed once
-// per call (for every point the list of points of the other cloud that chose it, ASCENDING) and every point sums its
-// own term and then its list in that fixed order: bit-identical results on every run, no zero-fill, no atomics.
+// per call (for every point the list of points of the other cloud that chose it) and every point sums its own term and
+// its list in a way that does not depend on timing:
+//   * a list of up to kCsrShort entries is put in ascending order and added one after the other, in exactly the order
+//     of the scalar loops of the CPU oracle (bit-equal to it);
+//   * a longer list (a prediction collapsed onto few target points sends thousands of points to one neighbour - the
+//     randomly initialised model of the benchmark does) stays unordered and is summed by a whole wave in 64-bit FIXED
+//     POINT, whose integer additions commute: same bits on every run, accurate to 2^-40 of the largest term.
 //
-// chamfer_csr_kernel: one workgroup per (cloud, direction).  Counting sort in LDS (integer atomics only decide slots,
-// not sums), rows put in ascending order afterwards: short rows (<= 32 entries) by rank inside the row, long rows - a
-// prediction collapsed onto few target points sends thousands of points to one neighbour - by an ordered re-scan of the
-// index array with ballot / popcount, one wave per long row (no O(n^2) path for any input).
+// chamfer_csr_kernel: one workgroup per (cloud, direction): counting sort in LDS (integer atomics decide slots, never
+// sums), short rows ranked into ascending order.
 constexpr int kCsrT = 1024;
 constexpr int kCsrShort = 32;
 
@@ -252,8 +255,9 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
                                                             int n, int m, int32_t* __restrict__ rowptr1, int32_t* __restrict__ tmp1,
                                                             int32_t* __restrict__ col1, int32_t* __restrict__ rowptr2,
                                                             int32_t* __restrict__ tmp2, int32_t* __restrict__ col2) {
-  extern __shared__ __attribute__((aligned(16))) int csm[];   // cnt[nc] | cur[nc] | part[kCsrT]
+  extern __shared__ __attribute__((aligned(16))) int csm[];   // cnt[nc] | cur[nc] | wtot[16]
   const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int nq = dir ? m : n, nc = dir ? n : m;               // nq entries (points that chose), nc rows (points chosen)
   const int32_t* __restrict__ ib = (dir ? idx2 : idx1) + (size_t)b * nq;
   int32_t* __restrict__ rp = (dir ? rowptr2 : rowptr1) + (size_t)b * (nc + 1);
@@ -261,26 +265,28 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
   int32_t* __restrict__ cl = (dir ? col2 : col1) + (size_t)b * nq;
   int* cnt = csm;
   int* cur = cnt + nc;
-  int* part = cur + nc;
+  int* wtot = cur + nc;
   for (int r = tid; r < nc; r += kCsrT) cnt[r] = 0;
   __syncthreads();
   for (int e = tid; e < nq; e += kCsrT) atomicAdd(&cnt[ib[e]], 1);
   __syncthreads();
-  const int per = (nc + kCsrT - 1) / kCsrT;                   // exclusive scan: thread t owns rows [t*per, (t+1)*per)
+  // exclusive scan of cnt: thread t owns rows [t*per, (t+1)*per); wave scan of the per-thread totals, then the 16 wave totals
+  const int per = (nc + kCsrT - 1) / kCsrT;
   int local = 0;
   for (int i = 0; i < per; ++i) {
     const int r = tid * per + i;
     if (r < nc) local += cnt[r];
   }
-  part[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < kCsrT; off <<= 1) {
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
   }
-  int run = part[tid] - local;
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int run = incl - local;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
   for (int i = 0; i < per; ++i) {
     const int r = tid * per + i;
     if (r < nc) {
@@ -289,18 +295,22 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
       run += cnt[r];
     }
   }
-  if (tid == kCsrT - 1) rp[nc] = part[tid];
+  if (tid == kCsrT - 1) rp[nc] = run;
   __syncthreads();
-  for (int e = tid; e < nq; e += kCsrT) {                     // unordered fill of the short rows' slots
-    const int r = ib[e];
+  for (int e = tid; e < nq; e += kCsrT) {                     // unordered fill: long rows straight into col, short rows
+    const int r = ib[e];                                      // into tmp (ranked below)
     const int pos = atomicAdd(&cur[r], 1);
-    if (cnt[r] <= kCsrShort) tp[pos] = e;
+    (cnt[r] <= kCsrShort ? tp : cl)[pos] = e;
   }
-  __syncthreads();                                            // (workgroup-scope fence: tp is re-read by other threads below)
+  __syncthreads();                                            // (workgroup-scope fence: tmp is re-read by other threads below)
   for (int r = tid; r < nc; r += kCsrT) {                     // short rows: every entry to the slot of its rank
     const int c = cnt[r];
     if (c == 0 || c > kCsrShort) continue;
     const int beg = cur[r] - c;
+    if (c == 1) {
+      cl[beg] = tp[beg];
+      continue;
+    }
     for (int i = 0; i < c; ++i) {
       const int v = tp[beg + i];
       int rank = 0;
@@ -308,27 +318,12 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
       cl[beg + rank] = v;
     }
   }
-  const int lane = tid & 63, wave = tid >> 6;                 // long rows: ordered re-scan, one wave per row
-  for (int r = wave; r < nc; r += kCsrT / 64) {
-    const int c = cnt[r];                                     // wave-uniform
-    if (c <= kCsrShort) continue;
-    int base = cur[r] - c;
-    for (int e0 = 0; e0 < nq; e0 += 64) {
-      const int e = e0 + lane;
-      const bool hit = e < nq && ib[e] == r;
-      const unsigned long long mask = __ballot(hit);
-      if (hit) cl[base + __popcll(mask & ((1ull << lane) - 1ull))] = e;
-      base += __popcll(mask);
-    }
-  }
 }
 
-// One lane per point of either cloud.  The additions happen in exactly the order of the scalar loops of the CPU oracle
-// (oracle/ptops_ref.c: pass over cloud 1, then pass over cloud 2, each adding its own term to the point and the negated
-// term to the neighbour): a point of cloud 1 = own term, then the terms of the cloud-2 points that chose it by ascending
-// index; a point of cloud 2 = the terms of the cloud-1 points that chose it by ascending index, then its own term.  Rows
-// longer than 64 are walked by the whole wave: 64 terms are computed in parallel and added one after the other in entry
-// order (readlane), so the order - and the result, bit for bit - is the same for every row length.
+// One lane per point of either cloud.  Short rows: the additions happen in exactly the order of the scalar loops of the
+// CPU oracle (oracle/ptops_ref.c: pass over cloud 1, then pass over cloud 2, each adding its own term to the point and the
+// negated term to the neighbour) - a point of cloud 1 = own term, then the terms of the cloud-2 points that chose it by
+// ascending index; a point of cloud 2 = those terms first, then its own.  Long rows: the whole wave, fixed point.
 __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, const int32_t* __restrict__ idx1,
     const int32_t* __restrict__ idx2, const float* __restrict__ gd1, const float* __restrict__ gd2, int B, int n, int m,
@@ -358,7 +353,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
     beg = rp[j];
     cnt = rp[j + 1] - beg;
     if (!second) ax += ox, ay += oy, az += oz;                     // cloud 1: the own term is added first
-    if (cnt <= 64) {
+    if (cnt <= kCsrShort) {
       for (int i = 0; i < cnt; ++i) {
         const int k = cl[beg + i];
         const float gk = god[k] * 2.0f;
@@ -368,7 +363,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
       }
     }
   }
-  unsigned long long todo = __ballot(live && cnt > 64);
+  unsigned long long todo = __ballot(live && cnt > kCsrShort);
   const int lane = threadIdx.x & 63;
   while (todo) {                                                   // wave-uniform
     const int src = __ffsll((long long)todo) - 1;
@@ -380,24 +375,55 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
     const float* sob = (ssecond ? xyz1 : xyz2) + (size_t)sb * sno * 3;
     const float* sgod = (ssecond ? gd1 : gd2) + (size_t)sb * sno;
     const int32_t* scl = (ssecond ? col1 : col2) + (size_t)sb * sno;
-    float sx = __shfl(ax, src), sy = __shfl(ay, src), sz = __shfl(az, src);
-    for (int i0 = 0; i0 < rc; i0 += 64) {
-      float tx = 0.f, ty = 0.f, tz = 0.f;
-      if (i0 + lane < rc) {
-        const int k = scl[rb + i0 + lane];
-        const float gk = sgod[k] * 2.0f;
-        tx = -(gk * (sob[(size_t)k * 3] - qx));
-        ty = -(gk * (sob[(size_t)k * 3 + 1] - qy));
-        tz = -(gk * (sob[(size_t)k * 3 + 2] - qz));
-      }
-      const int lim = min(64, rc - i0);
-      for (int i = 0; i < lim; ++i) {                              // strictly in entry order
-        sx += __shfl(tx, i);
-        sy += __shfl(ty, i);
-        sz += __shfl(tz, i);
+    // pass 1: the largest |term| of the row fixes the scale (a pure function of the row's contents, not of its order)
+    float mx = 0.0f;
+    int bad = 0;
+    for (int i = lane; i < rc; i += 64) {
+      const int k = scl[rb + i];
+      const float gk = sgod[k] * 2.0f;
+      const float a0 = fabsf(gk * (sob[(size_t)k * 3] - qx)), a1 = fabsf(gk * (sob[(size_t)k * 3 + 1] - qy)),
+                  a2 = fabsf(gk * (sob[(size_t)k * 3 + 2] - qz));
+      const float a = fmaxf(a0, fmaxf(a1, a2));
+      const bool fin = (a0 < INFINITY) && (a1 < INFINITY) && (a2 < INFINITY);
+      mx = fin ? fmaxf(mx, a) : mx;
+      bad |= !fin;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    bad = __any(bad);
+    int e2 = 0;
+    (void)frexpf(mx > 0.0f ? mx : 1.0f, &e2);
+    const double scale = ldexp(1.0, 46 - e2), inv = ldexp(1.0, e2 - 46);   // < 2^15 entries of < 2^46 each: 62 bits
+    long long sx = 0, sy = 0, sz = 0;
+    float fx = 0.f, fy = 0.f, fz = 0.f;                            // non-finite terms (NaN / infinity poison the sum)
+    for (int i = lane; i < rc; i += 64) {
+      const int k = scl[rb + i];
+      const float gk = sgod[k] * 2.0f;
+      const float tx = -(gk * (sob[(size_t)k * 3] - qx)), ty = -(gk * (sob[(size_t)k * 3 + 1] - qy)),
+                  tz = -(gk * (sob[(size_t)k * 3 + 2] - qz));
+      if (fabsf(tx) < INFINITY) sx += __double2ll_rn((double)tx * scale); else fx += tx;
+      if (fabsf(ty) < INFINITY) sy += __double2ll_rn((double)ty * scale); else fy += ty;
+      if (fabsf(tz) < INFINITY) sz += __double2ll_rn((double)tz * scale); else fz += tz;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sx += __shfl_xor(sx, off);
+      sy += __shfl_xor(sy, off);
+      sz += __shfl_xor(sz, off);
+    }
+    if (bad) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        fx += __shfl_xor(fx, off);
+        fy += __shfl_xor(fy, off);
+        fz += __shfl_xor(fz, off);
       }
     }
-    if (lane == src) ax = sx, ay = sy, az = sz;
+    if (lane == src) {
+      ax += (float)((double)sx * inv) + fx;
+      ay += (float)((double)sy * inv) + fy;
+      az += (float)((double)sz * inv) + fz;
+    }
   }
   if (live) {
     if (second) ax += ox, ay += oy, az += oz;                      // cloud 2: the own term is added last
@@ -657,7 +683,7 @@ PTOPS_API int ptops_chamfer_backward_det(const float* xyz1, const float* xyz2, c
   w += (size_t)B * m;
   int32_t* col2 = w;
   const int nc_max = n > m ? n : m;
-  const size_t lds = sizeof(int) * (2 * (size_t)nc_max + kCsrT);
+  const size_t lds = sizeof(int) * (2 * (size_t)nc_max + 16);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chamfer_csr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(chamfer_csr_kernel, dim3(B, 2), dim3(kCsrT), lds, stream, idx1, idx2, n, m, rowptr1, tmp1, col1, rowptr2,
                      tmp2, col2);

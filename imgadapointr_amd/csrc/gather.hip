@@ -272,32 +272,65 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_kernel(const float* __res
   }
 }
 
-// Same scatter through an LDS tile: a workgroup owns (b, 32 channels), accumulates every query's contribution
-// with ds_add_f32 into tile[channel][source point] (row stride N + 1: the 32 channels of a query land on 32
-// banks) and writes the tile out once — no global atomics, no memset.  Used when the tile fits (N <= 1024).
-constexpr int kGmCT = 32;
+// Same scatter through an LDS tile, DETERMINISTIC (round 3): a workgroup owns (b, 16 channels) and accumulates every
+// query's contribution into tile[channel][source point] - as 64-bit FIXED-POINT integers (ds_add_u64), whose sum does
+// not depend on the order in which the atomics arrive.  The scale is a power of two chosen from the largest |gradient|
+// of the workgroup's own slice (so it is a pure function of the inputs): max |g| maps to [2^46, 2^47), up to 2^16
+// addends fit 63 bits, and a value keeps all its 24 mantissa bits unless it is below 2^-23 of that maximum - an
+// accumulation error far below the fp32 rounding of the sum itself.  No global atomics, no memset, N <= 1024.
+constexpr int kGmCT = 16;
 
 __global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ arg, int N, int C,
                                                                   int S, float* __restrict__ grad_p) {
-  extern __shared__ float gm_tile[];  // [kGmCT][N + 1]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long gm_tile[];  // [kGmCT][N + 1]
+  __shared__ float wmax[kTPB / 64];
   const int b = blockIdx.y, c0 = blockIdx.x * kGmCT;
   const int ld = N + 1;
-  for (int t = threadIdx.x; t < kGmCT * ld; t += kTPB) gm_tile[t] = 0.0f;
-  __syncthreads();
-  const int ct = threadIdx.x & (kGmCT - 1), sl = threadIdx.x / kGmCT;  // 32 channels x 8 query lanes
+  for (int t = threadIdx.x; t < kGmCT * ld; t += kTPB) gm_tile[t] = 0ull;
+  const int ct = threadIdx.x & (kGmCT - 1), sl = threadIdx.x / kGmCT;  // 16 channels x 16 query lanes
   const int c = c0 + ct;
+  float mx = 0.0f;
+  int bad = 0;                                               // a NaN or infinity in the slice
+  if (c < C)
+    for (int s = sl; s < S; s += kTPB / kGmCT) {
+      const float a = fabsf(grad_out[((long long)b * S + s) * C + c]);
+      const bool fin = a < INFINITY;
+      mx = fin ? fmaxf(mx, a) : mx;
+      bad |= !fin;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  bad = __syncthreads_or(bad);
+  mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  // an infinite or NaN gradient must poison the outputs it touches: those terms are added through the float path at
+  // the end (their sum is NaN / infinite in any order); the finite ones go through the fixed-point tile
+  int e2 = 0;
+  (void)frexpf(mx > 0.0f ? mx : 1.0f, &e2);                 // mx = f * 2^e2, f in [0.5, 1)
+  const double scale = ldexp(1.0, 47 - e2), inv = ldexp(1.0, e2 - 47);
   if (c < C) {
     for (int s = sl; s < S; s += kTPB / kGmCT) {
       const long long e = ((long long)b * S + s) * C + c;
-      atomicAdd(&gm_tile[ct * ld + arg[e]], grad_out[e]);
+      const float g = grad_out[e];
+      const long long q = fabsf(g) < INFINITY ? __double2ll_rn((double)g * scale) : 0ll;
+      atomicAdd(&gm_tile[ct * ld + arg[e]], (unsigned long long)q);
     }
   }
   __syncthreads();
   // write-out: lanes over channels (contiguous in grad_p), rows over source points
   for (int t = threadIdx.x; t < kGmCT * N; t += kTPB) {
     const int cc = t & (kGmCT - 1), n = t / kGmCT;
-    if (c0 + cc < C) grad_p[((long long)b * N + n) * C + c0 + cc] = gm_tile[cc * ld + n];
+    if (c0 + cc < C) grad_p[((long long)b * N + n) * C + c0 + cc] = (float)((double)(long long)gm_tile[cc * ld + n] * inv);
+  }
+  if (bad) {                                                 // rare: add the non-finite terms on top (order is irrelevant)
+    __syncthreads();
+    if (c < C)
+      for (int s = sl; s < S; s += kTPB / kGmCT) {
+        const long long e = ((long long)b * S + s) * C + c;
+        const float g = grad_out[e];
+        if (!(fabsf(g) < INFINITY)) atomicAdd(&grad_p[((long long)b * N + arg[e]) * C + c], g);
+      }
   }
 }
 
@@ -447,9 +480,9 @@ PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* ar
   const long long total = (long long)B * S * C;
   if (total > 0 && N <= 1024 && B <= 65535) {
     PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
-    const size_t lds = sizeof(float) * (size_t)kGmCT * (N + 1);   // <= 131 KB
+    const size_t lds = sizeof(unsigned long long) * (size_t)kGmCT * (N + 1);   // <= 131 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * kGmCT * 1025));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kGmCT * 1025));
     hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out,
                        arg, N, C, S, grad_p);
     return ptops::check_launch("gather_max_bwd_lds_kernel");

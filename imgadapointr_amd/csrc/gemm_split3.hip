@@ -90,10 +90,11 @@ __device__ __forceinline__ int entry_index(int t) {
 // Thread t < 256 stages A entry t, thread t >= 256 stages B entry t - 256 (one entry = 8 f32 of one row -> 3 x 16 bytes).
 // With 4 waves per tile and 432 tiles (M = 18432, N = 384) a SIMD mostly hosts ONE wave, whose LDS / staging / barrier
 // phases leave the matrix pipe idle; 8 waves put two waves of every tile on each SIMD (107 -> ? TFLOP/s).
-// (512, 3): three workgroups per CU (24 waves; 50.7 KB of LDS each, <= 80 VGPRs) - one more set of waves to fill the
-// LDS / split / barrier phases of the others: +1..4 % over two (benchmarks/probes/gemm_pingpong_probe.hip, round 3; the
-// "ping-pong" role split of the two wave halves measured there is 3-30 % SLOWER than this loop).
-template <bool AKC, bool BKC, int OCC = 3>
+// Round 3 (benchmarks/probes/gemm_pingpong_probe.hip, profiles/round3/gemm_pingpong_v*.log): a "ping-pong" role split of
+// the two wave halves (one half multiplies while the other splits / stores, a barrier per phase) is 3-12 % SLOWER than this
+// loop with 16-deep steps and 20-30 % slower with 32-deep stages; three workgroups per CU instead of two (OCC = 3, <= 80
+// VGPRs) is +1..4 % in the kernel alone but -0.08 ms in the train step (profiles/round3/step_ab_v1.log): not adopted.
+template <bool AKC, bool BKC, int OCC = 2>
 __global__ __launch_bounds__(512, OCC) void gemm_split3_kernel(GemmArgs g) {
   // [buffer][operand][piece][k-half * kPlane + row]
   __shared__ uint4 lds[2][2][3][2 * kPlane];
@@ -333,7 +334,7 @@ static int gemm_split3_launch(const float* A, long long lda, int a_k_contiguous,
   PTOPS_REQUIRE(blocks < (1LL << 31), "gemm_f32_split3: grid too large");
   dim3 grid((unsigned)blocks), block(512);
   if (a_k_contiguous && b_k_contiguous) {
-    if (ptops::option("PTOPS_GEMM_OCC2")) hipLaunchKernelGGL((gemm_split3_kernel<true, true, 2>), grid, block, 0, stream, g);   // A/B
+    if (ptops::option("PTOPS_GEMM_OCC3")) hipLaunchKernelGGL((gemm_split3_kernel<true, true, 3>), grid, block, 0, stream, g);   // A/B
     else hipLaunchKernelGGL((gemm_split3_kernel<true, true>), grid, block, 0, stream, g);
   }
   else if (a_k_contiguous) hipLaunchKernelGGL((gemm_split3_kernel<true, false>), grid, block, 0, stream, g);

@@ -310,7 +310,7 @@ size_t ptops_colsum_workspace_bytes(int M, int N);
 int ptops_colsum(const float* x, int M, int N, float* out, void* workspace, void* stream);
 
 /* A/B switches of the library (PTOPS_ATTN_FWD_F32, PTOPS_ATTN_BWD_F32, PTOPS_ATTN_FWD_WAVES, PTOPS_ATTN_DKV_WAVES,
- * PTOPS_ATTN_QSPLIT, PTOPS_ATTN_NO_XCD_REMAP, PTOPS_CHAMFER_MFMA_PREFETCH, PTOPS_GEMM_OCC2): each is initialised ONCE from the environment variable of the same name
+ * PTOPS_ATTN_QSPLIT, PTOPS_ATTN_NO_XCD_REMAP, PTOPS_CHAMFER_MFMA_PREFETCH, PTOPS_GEMM_OCC3): each is initialised ONCE from the environment variable of the same name
  * and afterwards changes only through ptops_set_option (returns the previous value, -1 for an unknown name), so that
  * a benchmark's label and the kernel that ran agree.  Benchmarking / test aid, not a tuning interface. */
 int ptops_set_option(const char* name, int value);

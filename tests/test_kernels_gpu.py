@@ -176,8 +176,9 @@ def test_chamfer_backward(native, ref, B, n, m, kind):
 
 def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
     """Rows of every length: a prediction collapsed onto a few target points sends thousands of points to one
-    neighbour (the long-row paths of the transposition and of the summation), mixed with isolated points and points
-    nobody chose; a full-size call (B = 4, 16384 x 16384) for the LDS limits."""
+    neighbour (the long-row path: unordered list, fixed-point sum by a whole wave), mixed with isolated points and points
+    nobody chose; a full-size call (B = 4, 16384 x 16384) for the LDS limits.  Points whose list has at most 32 entries
+    must equal the oracle bit for bit (same order of additions); the others to fp32 rounding; every run the same bits."""
     rng = np.random.default_rng(99)
     for B, n, m, centres in ((2, 5000, 3000, 3), (1, 16384, 16384, 40), (4, 16384, 16384, 0), (2, 70, 16384, 1)):
         b = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
@@ -190,14 +191,23 @@ def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
             a = rng.random((B, n, 3), dtype=np.float32) - 0.5
         a = np.ascontiguousarray(a, dtype=np.float32)
         _, _, j1, j2 = ref.chamfer_forward(a, b)
+        rows2 = np.stack([np.bincount(j1[i], minlength=m) for i in range(B)])      # list lengths of the cloud-2 points
+        rows1 = np.stack([np.bincount(j2[i], minlength=n) for i in range(B)])
         if centres and n > 1000:
-            assert np.bincount(j1[0], minlength=m).max() > 64          # the long-row path is really taken
+            assert rows2.max() > 64                                              # the long-row path is really taken
         g1 = rng.standard_normal((B, n)).astype(np.float32)
         g2 = rng.standard_normal((B, m)).astype(np.float32)
         ra, rb = ref.chamfer_backward(a, b, j1, j2, g1, g2)
         da, db = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=True)
-        assert np.array_equal(da.cpu().numpy().view(np.uint32), ra.view(np.uint32)), (B, n, m)
-        assert np.array_equal(db.cpu().numpy().view(np.uint32), rb.view(np.uint32)), (B, n, m)
+        ea, eb = native.chamfer_backward(_t(a), _t(b), _t(j1), _t(j2), _t(g1), _t(g2), deterministic=True)
+        assert torch.equal(da, ea) and torch.equal(db, eb)
+        da, db = da.cpu().numpy(), db.cpu().numpy()
+        for got, want, rows in ((da, ra, rows1), (db, rb, rows2)):
+            short = rows <= 32
+            assert np.array_equal(got[short].view(np.uint32), want[short].view(np.uint32)), (B, n, m)
+            if (~short).any():
+                scale = np.abs(want[~short]).max()
+                assert np.abs(got[~short] - want[~short]).max() <= 1e-5 * scale + 1e-7, (B, n, m)
 
 
 FPS_CASES = [(2, 2048, 512, "uniform"), (3, 512, 256, "uniform"), (2, 2048, 256, "shell"), (2, 2048, 64, "shell"),
@@ -295,6 +305,24 @@ def test_gather_max(native, ref, B, N, C, S, k):
     go = rng.standard_normal(ro.shape).astype(np.float32)
     g = native.gather_max_backward(_t(go), _t(ra), N).cpu().numpy()
     np.testing.assert_allclose(g, ref.gather_max_backward(go, ra, N), rtol=1e-5, atol=1e-5)
+    # fixed-point accumulation (csrc/gather.hip): the same bits on every run, a float64 sum to fp32 rounding, heavy
+    # collisions (every query choosing the same few source points) included; NaN / infinity poison what they touch
+    hot = np.minimum(ra, 3).astype(np.int32)
+    want = np.zeros((B, N, C), np.float64)
+    for b in range(B):
+        for s_ in range(S):
+            np.add.at(want[b], (hot[b, s_], np.arange(C)), go[b, s_].astype(np.float64))
+    runs = [native.gather_max_backward(_t(go), _t(hot), N) for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    err = np.abs(runs[0].cpu().numpy().astype(np.float64) - want)
+    assert err.max() <= 2.0 ** -22 * np.abs(want).max() + 1e-30, err.max()
+    bad = go.copy()
+    bad[0, 1, 2], bad[B - 1, 0, 0] = np.nan, np.inf
+    gb = native.gather_max_backward(_t(bad), _t(hot), N).cpu().numpy()
+    assert np.isnan(gb[0, hot[0, 1, 2], 2]) and np.isinf(gb[B - 1, hot[B - 1, 0, 0], 0])
+    ok = np.ones_like(gb, dtype=bool)
+    ok[0, hot[0, 1, 2], 2] = ok[B - 1, hot[B - 1, 0, 0], 0] = False
+    np.testing.assert_allclose(gb[ok], runs[0].cpu().numpy()[ok], rtol=1e-5, atol=1e-5)
 
 
 def test_cpu_tensor_is_refused(native):
@@ -676,9 +704,14 @@ def test_fused_edge_conv_matches_literal_chain(native, B, N):
         # evaluation, fused or literal; that moves one O(1) contribution of this loss to another source point and fans
         # out through the earlier stages.  Each form is therefore judged against float64 (relative L2, flip-tolerant):
         # the fused kernels must be as close to it as the reference's literal chain is.
-        ea = ((a.double() - r).norm() / r.norm().clamp_min(1e-12)).item()
-        eb = ((b.double() - r).norm() / r.norm().clamp_min(1e-12)).item()
-        assert ea <= 1.5 * eb + 1e-5 and max(ea, eb) < 2e-2, (name, ea, eb)
+        # (a flip is a genuine O(1) change of a handful of elements, in whichever fp32 form it happens - on one box the
+        # literal chain matched all of float64's selections and the fused one flipped one, 2.8e-3 relative L2 - so the
+        # criterion is element-wise with an allowance for the few elements a flip touches, plus a relative-L2 cap)
+        tol = 1e-4 * max(1.0, r.abs().max().item())
+        for form, t_ in (("fused", a), ("literal", b)):
+            off = ((t_.double() - r).abs() > tol).double().mean().item()
+            rel = ((t_.double() - r).norm() / r.norm().clamp_min(1e-12)).item()
+            assert off <= 2e-3 and rel < 2e-2, (name, form, off, rel)
 
 
 @pytest.mark.parametrize("B,C,Nq,Nk,k,G", [(2, 32, 300, 700, 16, 4), (3, 64, 512, 512, 8, 4), (1, 128, 256, 512, 16, 4)])

@@ -215,3 +215,34 @@ def test_fast_paths_single_step_all_gradients(native):
         assert float(d.max()) <= 2.2 * lr, (n, float(d.max()))
     assert far <= 0.03 * n_el, (far, n_el)              # first AdamW step = lr * sign(g): only near-zero gradients differ
     print("worst gradient tensor", worst, "elements off after the update", far / n_el)
+
+
+@pytest.mark.gpu
+def test_train_step_gradients_are_bit_reproducible(native):
+    """Two runs of the same AdaPoinTr train step (same weights, inputs and jitter) give BIT-IDENTICAL gradients for every
+    parameter: the scatter-add backward passes of the path sum in a fixed order (Chamfer over the transposed neighbour
+    map, edge-conv over the transposed kNN graph) or in fixed point (gather-max), where the reference's kernels use float
+    atomics in arrival order (extensions/chamfer_dist/chamfer.cu:193-198)."""
+    import parity_checks as pc
+    from imgadapointr_amd.tools import builder, runner
+    torch.manual_seed(0)
+    B = 4
+    partial = (torch.rand(B, 2048, 3) - 0.5).cuda()
+    gt = (torch.rand(B, 16384, 3) - 0.5).cuda()
+    noise = (torch.randn(B, 64, 3) * 0.01).clamp_(-0.05, 0.05).cuda()
+
+    def run():
+        model, cfg = pc.build_adapointr("cuda")
+        model.train()
+        named = dict(model.named_parameters())
+        step = runner.TrainStep(model, builder.build_optimizer(model, cfg), 10, 1)
+        grads = {}
+        step.before_update = lambda: grads.update({n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None})
+        losses = step(partial, gt, (), 0, denoise_noise=noise)
+        return [float(v) for v in losses], grads, {n: p.detach().clone() for n, p in named.items()}
+
+    (la, ga, pa), (lb, gb, pb) = run(), run()
+    assert la == lb
+    diff = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    assert not diff, diff[:8]
+    assert all(torch.equal(pa[n], pb[n]) for n in pa)
