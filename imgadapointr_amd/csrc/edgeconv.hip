@@ -401,12 +401,17 @@ __global__ __launch_bounds__(kTPB) void edge_gather_dp_kernel(
     float acc[CT], sel[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = 0.0f, sel[ct] = 0.0f;
+    int prev = -1;
     for (int e = beg; e < end; ++e) {
       const int q = gc[e];
+      // a query that lists this source point more than once (never a kNN graph, but legal input) contributes one edge
+      // per listing to the dense term and its selected value ONCE; the row is sorted, so repeats are adjacent
+      const bool first = q != prev;
+      prev = q;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         acc[ct] += rt[ct * Nq + q];
-        sel[ct] += sn[ct * Nq + q] == (uint16_t)n ? st[ct * Nq + q] : 0.0f;
+        sel[ct] += (first && sn[ct * Nq + q] == (uint16_t)n) ? st[ct * Nq + q] : 0.0f;
       }
     }
 #pragma unroll

@@ -491,7 +491,16 @@ class DGCNN_Grouper(nn.Module):
         """x [B,N,3], num e.g. [512, 256] -> coor [B,num[1],3], f [B,num[1],128]."""
         x = x.transpose(-1, -2).contiguous()
         coor = x
-        f = self.input_trans(x)
+        # Conv1d(3 -> 8, kernel 1) as the matrix product it is: the weight gradient of aten's convolution backward is the
+        # one non-deterministic kernel of the step on this stack (differs in the last bits from run to run); two batched
+        # GEMMs are reproducible.  Same parameters, same values.
+        it = self.input_trans
+        if isinstance(it, nn.Conv1d) and it.kernel_size == (1,) and it.groups == 1 and it.stride == (1,):
+            f = torch.matmul(it.weight.squeeze(-1), x)
+            if it.bias is not None:
+                f = f + it.bias.view(1, -1, 1)
+        else:
+            f = it(x)
 
         f = self.edge_conv(self.layer1, coor, f, coor, f)
 
