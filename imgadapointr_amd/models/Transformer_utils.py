@@ -554,6 +554,38 @@ class _MFMASelfAttention(torch.autograd.Function):
         return g, None, None, None
 
 
+class _MFMAKVAttention(torch.autograd.Function):
+    """Cross attention on a PACKED key / value projection kv [B,M,2,h,64] (one GEMM for k_map and v_map): the backward
+    writes dk / dv straight into one [B,M,2,h,64] allocation and returns it as the gradient of kv - contiguous
+    [B*M, 2*C] rows for the projection's backward, where two separate projections received two strided slices of it
+    (a copy each for the bias column sums, two GEMMs each way instead of one)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale):
+        k, v = kv.permute(2, 0, 3, 1, 4).unbind(0)
+        out, lse2 = _native.attention_forward(q, k, v, 0, k.size(2), scale)
+        ctx.save_for_backward(q, kv, out, lse2)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, kv, out, lse2 = ctx.saved_tensors
+        B, H, Nq, _ = q.shape
+        k, v = kv.permute(2, 0, 3, 1, 4).unbind(0)
+        gq = torch.empty((B, Nq, H, 64), dtype=q.dtype, device=q.device).transpose(1, 2)
+        gkv = torch.empty_like(kv)
+        gk, gv = gkv.permute(2, 0, 3, 1, 4).unbind(0)
+        _native.attention_backward(q, k, v, out, grad_out.contiguous(), lse2, 0, k.size(2), ctx.scale, gq, gk, gv,
+                                   fused=(USE_MFMA_ATTENTION_BWD == "fused"))
+        return gq, gkv, None
+
+
+# CrossAttention: k_map and v_map (same input, separate parameters in the reference and in the state dict) as ONE
+# [2C, C] projection on the concatenated weights; PTOPS_FUSED_KV=0 keeps the two GEMMs
+FUSED_KV_PROJECTION = os.environ.get("PTOPS_FUSED_KV", "1") != "0"
+
+
 def _attend(q, k, v, scale, mask, attn_drop, mask_split=None):
     """q [B,h,N,d], k/v [B,h,M,d]; mask bool [N,M] with True = blocked (reference convention);
     mask_split = (split_q, limit_k) when the mask is the block mask "queries < split_q do not see
@@ -633,6 +665,17 @@ class CrossAttention(nn.Module):
         NK = k.size(1)
         h = self.num_heads
         q = self.q_map(q).view(B, N, h, C // h).permute(0, 2, 1, 3)
+        if (FUSED_KV_PROJECTION and USE_MFMA_ATTENTION and USE_MFMA_ATTENTION_BWD and C // h == 64 and k.is_cuda
+                and k.dtype == torch.float32 and _native.backend_for_testing() is None and torch.is_grad_enabled()
+                and self.k_map.bias is not None and self.v_map.bias is not None and B * NK >= 2048
+                and (self.attn_drop.p == 0.0 or not self.training) and N % 32 == 0 and NK % 32 == 0):
+            wkv = torch.cat([self.k_map.weight, self.v_map.weight], dim=0)            # [2C, C]: 1.2 MB, once per call
+            bkv = torch.cat([self.k_map.bias, self.v_map.bias], dim=0)
+            # the bias gradient travels on through cat's backward as two views: not a gradient autograd adopts unread
+            _native.fold_mark_plain(bkv.data_ptr())
+            kv = _LinearFn.apply(k.reshape(B * NK, -1), wkv, bkv).view(B, NK, 2, h, C // h)
+            x = _MFMAKVAttention.apply(q, kv, self.scale).reshape(B, N, C)
+            return self.proj_drop(self.proj(x))
         k = self.k_map(k).view(B, NK, h, C // h).permute(0, 2, 1, 3)
         v = self.v_map(v).view(B, NK, h, C // h).permute(0, 2, 1, 3)
         x = _attend(q, k, v, self.scale, None, self.attn_drop).reshape(B, N, C)

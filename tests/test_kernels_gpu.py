@@ -1217,3 +1217,41 @@ def test_clip_adamw_survives_a_state_dict_round_trip(native):
             our.load_state_dict(our.state_dict())
     for p, q in zip(a, b):
         assert float((p - q).detach().abs().max()) <= 1e-6 * float(p.detach().abs().max()) + 1e-7
+
+
+def test_cross_attention_fused_kv_projection(native):
+    """CrossAttention with k_map and v_map evaluated as ONE [2C, C] projection on the concatenated weights (packed
+    [B,M,2,h,64] keys / values, packed gradient) against the two separate projections: outputs and every gradient
+    (q, memory, all eight parameter tensors) to fp32 rounding, also under deferred folds with poisoned outputs."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(21)
+    B, N, M, C = 32, 576, 256, 384
+    ca = TU.CrossAttention(C, C, num_heads=6, qkv_bias=True).cuda()
+    for p in ca.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    q0 = torch.randn(B, N, C, device="cuda")
+    v0 = torch.randn(B, M, C, device="cuda")
+    w = torch.randn(B, N, C, device="cuda")
+    res = {}
+    old_poison = native.FOLD_POISON
+    native.FOLD_POISON = True
+    try:
+        for fused in (True, False):
+            TU.FUSED_KV_PROJECTION = fused
+            ca.zero_grad(set_to_none=True)
+            q, v = q0.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+            out = ca(q, v)
+            with native.deferred_folds(list(ca.parameters())):
+                (out * w).sum().backward()
+            res[fused] = [out.detach(), q.grad, v.grad] + [p.grad.clone() for p in ca.parameters()]
+    finally:
+        TU.FUSED_KV_PROJECTION = True
+        native.FOLD_POISON = old_poison
+    names = ["out", "dq", "dv"] + [n for n, _ in ca.named_parameters()]
+    for n, a, b in zip(names, res[True], res[False]):
+        assert torch.isfinite(a).all(), n
+        if "k_map.bias" in n:                      # zero in exact arithmetic (softmax shift invariance): rounding noise
+            assert float(a.abs().max()) < 1e-3 * float(res[False][names.index("v_map.bias")].abs().max()) + 1e-4
+            continue
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
