@@ -48,7 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--marker", default="chamfer_grad_kernel", help="kernel launched a fixed number of times per step")
+    ap.add_argument("--marker", default="adamw_update_kernel", help="kernel launched a fixed number of times per step")
     ap.add_argument("--top", type=int, default=25)
     a = ap.parse_args()
 

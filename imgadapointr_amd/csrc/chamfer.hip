@@ -268,7 +268,23 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
   int* wtot = cur + nc;
   for (int r = tid; r < nc; r += kCsrT) cnt[r] = 0;
   __syncthreads();
-  for (int e = tid; e < nq; e += kCsrT) atomicAdd(&cnt[ib[e]], 1);
+  // Counting with wave-aggregated atomics: the lanes of a wave that hold the same row elect a leader, which adds their
+  // number once.  A collapsed prediction sends thousands of entries to a few rows; 16384 LDS atomics on a handful of
+  // addresses serialise (the first version of this kernel took 0.8 ms on the benchmark's 16384^2 call), a few hundred
+  // aggregated ones do not.  With all-distinct rows the loop runs once per lane, ~2 k cycles per 64 entries.
+  for (int e0 = 0; e0 < nq; e0 += kCsrT) {
+    const int e = e0 + tid;
+    const bool valid = e < nq;
+    const int r = valid ? ib[e] : -1;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const int rl = __shfl(r, lead);
+      const unsigned long long same = __ballot(valid && r == rl);
+      if (lane == lead) atomicAdd(&cnt[rl], (int)__popcll(same));
+      todo &= ~same;
+    }
+  }
   __syncthreads();
   // exclusive scan of cnt: thread t owns rows [t*per, (t+1)*per); wave scan of the per-thread totals, then the 16 wave totals
   const int per = (nc + kCsrT - 1) / kCsrT;
@@ -297,10 +313,23 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
   }
   if (tid == kCsrT - 1) rp[nc] = run;
   __syncthreads();
-  for (int e = tid; e < nq; e += kCsrT) {                     // unordered fill: long rows straight into col, short rows
-    const int r = ib[e];                                      // into tmp (ranked below)
-    const int pos = atomicAdd(&cur[r], 1);
-    (cnt[r] <= kCsrShort ? tp : cl)[pos] = e;
+  for (int e0 = 0; e0 < nq; e0 += kCsrT) {                    // unordered fill (same aggregation): long rows straight
+    const int e = e0 + tid;                                   // into col, short rows into tmp (ranked below)
+    const bool valid = e < nq;
+    const int r = valid ? ib[e] : -1;
+    int pos = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const int rl = __shfl(r, lead);
+      const unsigned long long same = __ballot(valid && r == rl);
+      int base = 0;
+      if (lane == lead) base = atomicAdd(&cur[rl], (int)__popcll(same));
+      base = __shfl(base, lead);
+      if (valid && r == rl) pos = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
+    }
+    if (valid) (cnt[r] <= kCsrShort ? tp : cl)[pos] = e;
   }
   __syncthreads();                                            // (workgroup-scope fence: tmp is re-read by other threads below)
   for (int r = tid; r < nc; r += kCsrT) {                     // short rows: every entry to the slot of its rank
@@ -378,15 +407,26 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
     // pass 1: the largest |term| of the row fixes the scale (a pure function of the row's contents, not of its order)
     float mx = 0.0f;
     int bad = 0;
-    for (int i = lane; i < rc; i += 64) {
-      const int k = scl[rb + i];
-      const float gk = sgod[k] * 2.0f;
-      const float a0 = fabsf(gk * (sob[(size_t)k * 3] - qx)), a1 = fabsf(gk * (sob[(size_t)k * 3 + 1] - qy)),
-                  a2 = fabsf(gk * (sob[(size_t)k * 3 + 2] - qz));
-      const float a = fmaxf(a0, fmaxf(a1, a2));
-      const bool fin = (a0 < INFINITY) && (a1 < INFINITY) && (a2 < INFINITY);
-      mx = fin ? fmaxf(mx, a) : mx;
-      bad |= !fin;
+    // four entries per lane and iteration: their (dependent) index -> gradient / coordinate loads overlap
+    for (int i0 = lane; i0 < rc; i0 += 256) {
+      int kk[4];
+      float gg[4], cx[4], cy[4], cz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = scl[rb + min(i0 + 64 * u, rc - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gg[u] = sgod[kk[u]] * 2.0f;
+        cx[u] = sob[(size_t)kk[u] * 3], cy[u] = sob[(size_t)kk[u] * 3 + 1], cz[u] = sob[(size_t)kk[u] * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + 64 * u >= rc) continue;
+        const float a0 = fabsf(gg[u] * (cx[u] - qx)), a1 = fabsf(gg[u] * (cy[u] - qy)), a2 = fabsf(gg[u] * (cz[u] - qz));
+        const float a = fmaxf(a0, fmaxf(a1, a2));
+        const bool fin = (a0 < INFINITY) && (a1 < INFINITY) && (a2 < INFINITY);
+        mx = fin ? fmaxf(mx, a) : mx;
+        bad |= !fin;
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -396,14 +436,24 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
     const double scale = ldexp(1.0, 46 - e2), inv = ldexp(1.0, e2 - 46);   // < 2^15 entries of < 2^46 each: 62 bits
     long long sx = 0, sy = 0, sz = 0;
     float fx = 0.f, fy = 0.f, fz = 0.f;                            // non-finite terms (NaN / infinity poison the sum)
-    for (int i = lane; i < rc; i += 64) {
-      const int k = scl[rb + i];
-      const float gk = sgod[k] * 2.0f;
-      const float tx = -(gk * (sob[(size_t)k * 3] - qx)), ty = -(gk * (sob[(size_t)k * 3 + 1] - qy)),
-                  tz = -(gk * (sob[(size_t)k * 3 + 2] - qz));
-      if (fabsf(tx) < INFINITY) sx += __double2ll_rn((double)tx * scale); else fx += tx;
-      if (fabsf(ty) < INFINITY) sy += __double2ll_rn((double)ty * scale); else fy += ty;
-      if (fabsf(tz) < INFINITY) sz += __double2ll_rn((double)tz * scale); else fz += tz;
+    for (int i0 = lane; i0 < rc; i0 += 256) {
+      int kk[4];
+      float gg[4], cx[4], cy[4], cz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = scl[rb + min(i0 + 64 * u, rc - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gg[u] = sgod[kk[u]] * 2.0f;
+        cx[u] = sob[(size_t)kk[u] * 3], cy[u] = sob[(size_t)kk[u] * 3 + 1], cz[u] = sob[(size_t)kk[u] * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + 64 * u >= rc) continue;
+        const float tx = -(gg[u] * (cx[u] - qx)), ty = -(gg[u] * (cy[u] - qy)), tz = -(gg[u] * (cz[u] - qz));
+        if (fabsf(tx) < INFINITY) sx += __double2ll_rn((double)tx * scale); else fx += tx;
+        if (fabsf(ty) < INFINITY) sy += __double2ll_rn((double)ty * scale); else fy += ty;
+        if (fabsf(tz) < INFINITY) sz += __double2ll_rn((double)tz * scale); else fz += tz;
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -205,7 +205,7 @@ def test_fast_paths_single_step_all_gradients(native):
             worst = (n, err / ref_norm)
     # rounding-level differences flip a few arg-maxes (max-pools, kNN-free top-k of the query ranking), which moves single
     # tensors by up to ~1 % (tests/parity_checks.py); a wrong kernel moves its tensor by O(1)
-    assert n_checked >= 300 and worst[1] < 2e-2, worst
+    assert n_checked >= 280 and worst[1] < 2e-2, (worst, n_checked)
     lr = 1e-4
     far = n_el = 0
     for n in pb:
