@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from imgadapointr_amd import _native  # noqa: E402
+from imgadapointr_amd.models import Transformer_utils as TU  # noqa: E402
 from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
 from imgadapointr_amd.tools import builder, runner  # noqa: E402
 from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
@@ -42,6 +43,7 @@ def main():
             ("forward GEMM at three workgroups per CU", opt("PTOPS_GEMM_OCC3", 1)),
             ("attention without the XCD job order", opt("PTOPS_ATTN_NO_XCD_REMAP", 1)),
             ("immediate folds", attr(runner, "DEFER_FOLDS", False)),
+            ("k_map and v_map as two projections", attr(TU, "FUSED_KV_PROJECTION", False)),
             ("Chamfer MFMA with fragment prefetch", opt("PTOPS_CHAMFER_MFMA_PREFETCH", 1))]
     for _ in range(8):
         step(partial, gt)

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 // arrival order: gradients differ in the last bits from run to run.  Here the nearest-neighbour map is transposed once
 // per call (for every point the list of points of the other cloud that chose it) and every point sums its own term and
 // its list in a way that does not depend on timing:
-//   * a list of up to kCsrShort entries is put in ascending order and added one after the other, in exactly the order
+//   * a list of up to kCsrShort (8) entries is put in ascending order and added one after the other, in exactly the order
 //     of the scalar loops of the CPU oracle (bit-equal to it);
 //   * a longer list (a prediction collapsed onto few target points sends thousands of points to one neighbour - the
 //     randomly initialised model of the benchmark does) stays unordered and is summed by a whole wave in 64-bit FIXED
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 // chamfer_csr_kernel: one workgroup per (cloud, direction): counting sort in LDS (integer atomics decide slots, never
 // sums), short rows ranked into ascending order.
 constexpr int kCsrT = 1024;
-constexpr int kCsrShort = 32;
+constexpr int kCsrShort = 8;    // lists up to this length are ranked (c^2 loads) and added in the oracle's order
+constexpr int kCsrAgg = 6;      // leaders tried per wave-instruction before the remaining lanes add on their own
 
 __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
                                                             int n, int m, int32_t* __restrict__ rowptr1, int32_t* __restrict__ tmp1,
@@ -268,22 +269,26 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
   int* wtot = cur + nc;
   for (int r = tid; r < nc; r += kCsrT) cnt[r] = 0;
   __syncthreads();
-  // Counting with wave-aggregated atomics: the lanes of a wave that hold the same row elect a leader, which adds their
-  // number once.  A collapsed prediction sends thousands of entries to a few rows; 16384 LDS atomics on a handful of
-  // addresses serialise (the first version of this kernel took 0.8 ms on the benchmark's 16384^2 call), a few hundred
-  // aggregated ones do not.  With all-distinct rows the loop runs once per lane, ~2 k cycles per 64 entries.
+  // Counting with wave-aggregated atomics: lanes of a wave that hold the same row elect a leader, which adds their
+  // number once.  A collapsed prediction sends thousands of entries to a few rows, and 16384 LDS atomics on a handful of
+  // addresses serialise (0.8 ms on the benchmark's 16384^2 call without this).  At most kCsrAgg leaders are tried per
+  // wave-instruction - enough when a few rows dominate, a small fixed cost when all rows differ - and the lanes that
+  // are left add on their own.
   for (int e0 = 0; e0 < nq; e0 += kCsrT) {
     const int e = e0 + tid;
     const bool valid = e < nq;
     const int r = valid ? ib[e] : -1;
     unsigned long long todo = __ballot(valid);
-    while (todo) {
+    bool mine = valid;
+    for (int it = 0; it < kCsrAgg && todo; ++it) {
       const int lead = __ffsll((long long)todo) - 1;
       const int rl = __shfl(r, lead);
-      const unsigned long long same = __ballot(valid && r == rl);
+      const unsigned long long same = __ballot(mine && r == rl);
       if (lane == lead) atomicAdd(&cnt[rl], (int)__popcll(same));
+      mine = mine && r != rl;
       todo &= ~same;
     }
+    if (mine) atomicAdd(&cnt[r], 1);
   }
   __syncthreads();
   // exclusive scan of cnt: thread t owns rows [t*per, (t+1)*per); wave scan of the per-thread totals, then the 16 wave totals
@@ -319,16 +324,19 @@ __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __res
     const int r = valid ? ib[e] : -1;
     int pos = 0;
     unsigned long long todo = __ballot(valid);
-    while (todo) {
+    bool mine = valid;
+    for (int it = 0; it < kCsrAgg && todo; ++it) {
       const int lead = __ffsll((long long)todo) - 1;
       const int rl = __shfl(r, lead);
-      const unsigned long long same = __ballot(valid && r == rl);
+      const unsigned long long same = __ballot(mine && r == rl);
       int base = 0;
       if (lane == lead) base = atomicAdd(&cur[rl], (int)__popcll(same));
       base = __shfl(base, lead);
-      if (valid && r == rl) pos = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+      if (mine && r == rl) pos = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+      mine = mine && r != rl;
       todo &= ~same;
     }
+    if (mine) pos = atomicAdd(&cur[r], 1);
     if (valid) (cnt[r] <= kCsrShort ? tp : cl)[pos] = e;
   }
   __syncthreads();                                            // (workgroup-scope fence: tmp is re-read by other threads below)

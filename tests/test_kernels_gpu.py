@@ -170,7 +170,7 @@ def test_chamfer_backward(native, ref, B, n, m, kind):
     rows1 = np.stack([np.bincount(j2[i], minlength=n) for i in range(B)])      # how many points chose each point
     rows2 = np.stack([np.bincount(j1[i], minlength=m) for i in range(B)])
     for got, want, rows in ((da.cpu().numpy(), ra, rows1), (db.cpu().numpy(), rb, rows2)):
-        short = rows <= 32                                  # lists of <= 32 entries: the oracle's order, bit for bit
+        short = rows <= 8                                  # lists of <= 8 entries: the oracle's order, bit for bit
         assert np.array_equal(got[short].view(np.uint32), want[short].view(np.uint32))
         if (~short).any():                                  # longer lists: fixed-point sum, equal to fp32 rounding
             assert np.abs(got[~short] - want[~short]).max() <= 1e-5 * np.abs(want[~short]).max() + 1e-7
@@ -182,7 +182,7 @@ def test_chamfer_backward(native, ref, B, n, m, kind):
 def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
     """Rows of every length: a prediction collapsed onto a few target points sends thousands of points to one
     neighbour (the long-row path: unordered list, fixed-point sum by a whole wave), mixed with isolated points and points
-    nobody chose; a full-size call (B = 4, 16384 x 16384) for the LDS limits.  Points whose list has at most 32 entries
+    nobody chose; a full-size call (B = 4, 16384 x 16384) for the LDS limits.  Points whose list has at most 8 entries
     must equal the oracle bit for bit (same order of additions); the others to fp32 rounding; every run the same bits."""
     rng = np.random.default_rng(99)
     for B, n, m, centres in ((2, 5000, 3000, 3), (1, 16384, 16384, 40), (4, 16384, 16384, 0), (2, 70, 16384, 1)):
@@ -208,7 +208,7 @@ def test_chamfer_backward_deterministic_on_collapsed_clouds(native, ref):
         assert torch.equal(da, ea) and torch.equal(db, eb)
         da, db = da.cpu().numpy(), db.cpu().numpy()
         for got, want, rows in ((da, ra, rows1), (db, rb, rows2)):
-            short = rows <= 32
+            short = rows <= 8
             assert np.array_equal(got[short].view(np.uint32), want[short].view(np.uint32)), (B, n, m)
             if (~short).any():
                 scale = np.abs(want[~short]).max()
