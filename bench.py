@@ -372,9 +372,44 @@ def cpu_baseline(cfg, spec, budget_s=20.0):
             if time.time() - t0 > budget_s:
                 break
         dt = time.time() - t0
+        # the same step at the metric's batch size (one timed step after one warm-up) and the
+        # primitives alone at the hot-path shapes (per cloud, the oracle's OpenMP loops over `cores` threads)
+        extra_rows = {}
+        if spec["config"] == "configs[1]":
+            import numpy as np
+            B32 = BATCH
+            p32, g32 = torch.rand(B32, N_PARTIAL, 3) - 0.5, torch.rand(B32, N_GT, 3) - 0.5
+            step(p32, g32)
+            t1 = time.time()
+            step(p32, g32)
+            d32 = time.time() - t1
+            extra_rows["bs32"] = {"value": round(B32 / d32, 3), "unit": "clouds/s", "ms_per_step": round(d32 * 1e3, 1),
+                                  "sample": "1 full train step at bs=32 after 1 warm-up step"}
+            rng = np.random.default_rng(0)
+            ops = {}
+
+            def t_op(fn, reps):
+                fn()
+                t = time.time()
+                for _ in range(reps):
+                    fn()
+                return (time.time() - t) / reps * 1e3
+
+            Bo = 4
+            for n_, m_ in ((2048, 2048), (512, 16384), (16384, 16384)):
+                a_, b_ = rng.random((Bo, n_, 3), dtype=np.float32) - 0.5, rng.random((Bo, m_, 3), dtype=np.float32) - 0.5
+                ops[f"chamfer_forward {n_}x{m_}"] = round(t_op(lambda: oracle.chamfer_forward(a_, b_), 2) / Bo, 3)
+            for S_, N_, k_ in ((2048, 2048, 16), (512, 2048, 16), (512, 512, 16), (256, 512, 16), (256, 256, 8),
+                               (576, 256, 8), (512, 512, 8), (64, 16384, 32)):
+                c_, q_ = rng.random((Bo, N_, 3), dtype=np.float32) - 0.5, rng.random((Bo, S_, 3), dtype=np.float32) - 0.5
+                ops[f"knn {S_}x{N_} k{k_}"] = round(t_op(lambda: oracle.knn(k_, c_, q_), 3) / Bo, 3)
+            for N_, np_ in ((2048, 512), (512, 256), (2048, 256), (2048, 64)):
+                c_ = rng.random((Bo, N_, 3), dtype=np.float32) - 0.5
+                ops[f"fps {N_}->{np_}"] = round(t_op(lambda: oracle.furthest_point_sample(c_, np_), 3) / Bo, 3)
+            extra_rows["ops_ms_per_cloud"] = ops
     finally:
         _native.set_backend_for_testing(None)
-    return {"value": round(B * n / dt, 3), "unit": "clouds/s", "cores": cores, "kind": "port",
+    return {**extra_rows, "value": round(B * n / dt, 3), "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": f"{n} full train steps (fwd+loss+bwd+clip+AdamW) at bs={B}, 2048->16384, eager fp32 torch on "
                       f"{cores} threads, Chamfer/FPS/kNN/gathers through the CPU oracle (OpenMP)",
             "ms_per_step": round(dt / n * 1e3, 1)}

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 // sums), short rows ranked into ascending order.
 constexpr int kCsrT = 1024;
 constexpr int kCsrShort = 8;    // lists up to this length are ranked (c^2 loads) and added in the oracle's order
+constexpr int kCsrMid = 192;    // lists up to this length are summed by their own lane (fixed point), longer ones by the wave
 constexpr int kCsrAgg = 6;      // leaders tried per wave-instruction before the remaining lanes add on their own
 
 __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
@@ -398,9 +399,40 @@ __global__ __launch_bounds__(256) void chamfer_grad_det_kernel(
         ay += -(gk * (ob[(size_t)k * 3 + 1] - py));
         az += -(gk * (ob[(size_t)k * 3 + 2] - pz));
       }
+    } else if (cnt <= kCsrMid) {
+      // medium lists (a 512-point prediction against 16384 targets: ~32 entries per point): the lane walks its own list,
+      // unordered, in fixed point - every lane of the wave busy with a list of its own
+      float mx = 0.0f;
+      bool bad = false;
+      for (int i = 0; i < cnt; ++i) {
+        const int k = cl[beg + i];
+        const float gk = god[k] * 2.0f;
+        const float a0 = fabsf(gk * (ob[(size_t)k * 3] - px)), a1 = fabsf(gk * (ob[(size_t)k * 3 + 1] - py)),
+                    a2 = fabsf(gk * (ob[(size_t)k * 3 + 2] - pz));
+        const bool fin = (a0 < INFINITY) && (a1 < INFINITY) && (a2 < INFINITY);
+        mx = fin ? fmaxf(mx, fmaxf(a0, fmaxf(a1, a2))) : mx;
+        bad |= !fin;
+      }
+      int e2 = 0;
+      (void)frexpf(mx > 0.0f ? mx : 1.0f, &e2);
+      const double scale = ldexp(1.0, 46 - e2), inv = ldexp(1.0, e2 - 46);
+      long long sx = 0, sy = 0, sz = 0;
+      float fx = 0.f, fy = 0.f, fz = 0.f;
+      for (int i = 0; i < cnt; ++i) {
+        const int k = cl[beg + i];
+        const float gk = god[k] * 2.0f;
+        const float tx = -(gk * (ob[(size_t)k * 3] - px)), ty = -(gk * (ob[(size_t)k * 3 + 1] - py)),
+                    tz = -(gk * (ob[(size_t)k * 3 + 2] - pz));
+        if (fabsf(tx) < INFINITY) sx += __double2ll_rn((double)tx * scale); else fx += tx;
+        if (fabsf(ty) < INFINITY) sy += __double2ll_rn((double)ty * scale); else fy += ty;
+        if (fabsf(tz) < INFINITY) sz += __double2ll_rn((double)tz * scale); else fz += tz;
+      }
+      ax += (float)((double)sx * inv) + (bad ? fx : 0.0f);
+      ay += (float)((double)sy * inv) + (bad ? fy : 0.0f);
+      az += (float)((double)sz * inv) + (bad ? fz : 0.0f);
     }
   }
-  unsigned long long todo = __ballot(live && cnt > kCsrShort);
+  unsigned long long todo = __ballot(live && cnt > kCsrMid);
   const int lane = threadIdx.x & 63;
   while (todo) {                                                   // wave-uniform
     const int src = __ffsll((long long)todo) - 1;
