@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(
 // sums), short rows ranked into ascending order.
 constexpr int kCsrT = 1024;
 constexpr int kCsrShort = 8;    // lists up to this length are ranked (c^2 loads) and added in the oracle's order
-constexpr int kCsrMid = 192;    // lists up to this length are summed by their own lane (fixed point), longer ones by the wave
+constexpr int kCsrMid = 32;     // lists up to this length are summed by their own lane (fixed point), longer ones by the wave
 constexpr int kCsrAgg = 6;      // leaders tried per wave-instruction before the remaining lanes add on their own
 
 __global__ __launch_bounds__(kCsrT) void chamfer_csr_kernel(const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,

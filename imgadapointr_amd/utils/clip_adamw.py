@@ -15,9 +15,14 @@ _ROW = 64      # bytes per tensor row of the device table (ptops_adamw_row_bytes
 
 class ClipAdamW(torch.optim.AdamW):
     def __init__(self, params, **kwargs):
-        kwargs.pop("fused", None)
         self._plan = None                      # before super().__init__: it calls add_param_group
         self._ring = 0
+        params = list(params)
+        flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
+        # the stock `step()` (PTOPS_FUSED_ADAMW=0, an external caller, a parameter set `step_clipped` does not support) stays
+        # torch's fused multi-tensor AdamW where that exists, not the slower for-each form
+        if "fused" not in kwargs and flat and all(isinstance(p, torch.Tensor) and p.is_cuda and p.is_floating_point() for p in flat):
+            kwargs["fused"] = True
         super().__init__(params, **kwargs)
 
     def _sync_steps(self):
@@ -128,6 +133,10 @@ class ClipAdamW(torch.optim.AdamW):
             self._plan = self._make_plan(params, group_of)
         plan = self._plan
         self._opt_called = True                        # what LRScheduler's wrapper around step() records
+        # the hooks `Optimizer.step` would run (register_step_pre_hook / register_step_post_hook, global ones included)
+        from torch.optim.optimizer import _global_optimizer_post_hooks, _global_optimizer_pre_hooks
+        for hook in list(_global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
+            hook(self, (), {})
         rows = plan["rows"]
         rows[:, 1] = [p.grad.data_ptr() for p in params]
         plan["steps"] += 1.0
@@ -152,6 +161,8 @@ class ClipAdamW(torch.optim.AdamW):
         plan["rows_used"][slot] = True
         _native.adamw_clip_step(plan["rows_dev"], len(params), plan["chunks_dev"], plan["n_chunks"],
                                 float(max_norm) if max_norm else 0.0, beta1, beta2, eps, plan["partial"], plan["norm_coef"])
+        for hook in list(self._optimizer_step_post_hooks.values()) + list(_global_optimizer_post_hooks.values()):
+            hook(self, (), {})
         return plan["norm_coef"][0]
 
     def uniform_hyperparameters(self):
