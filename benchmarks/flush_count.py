@@ -1,0 +1,62 @@
+"""How many grouped weight-gradient launches / fold flushes one train step issues (a flush in the middle of backward
+splits the group), and what the step costs, for the fused and the separate k_map / v_map projections.
+
+    python benchmarks/flush_count.py
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from imgadapointr_amd import _native  # noqa: E402
+from imgadapointr_amd.models import Transformer_utils as TU  # noqa: E402
+from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
+from imgadapointr_amd.tools import builder, runner  # noqa: E402
+from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
+
+
+def main():
+    device = torch.device("cuda", 0)
+    _native.load()
+    enable_tuned_gemm()
+    cfg = bench.load_cfg()
+    torch.manual_seed(0)
+    model = build_model_from_cfg(cfg.model).to(device).train()
+    step = runner.TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
+    partial = (torch.rand(bench.BATCH, bench.N_PARTIAL, 3) - 0.5).to(device)
+    gt = (torch.rand(bench.BATCH, bench.N_GT, 3) - 0.5).to(device)
+    for _ in range(3):
+        step(partial, gt)
+    flush = _native.wgrad_flush
+    for fused in (True, False):
+        TU.FUSED_KV_PROJECTION = fused
+        step(partial, gt)
+        sizes = []
+
+        def spy():
+            if _native._wgrad_queue:
+                sizes.append((len(_native._wgrad_queue), sum(2e-9 * q[4] * q[5] * q[6] for q in _native._wgrad_queue)))
+            flush()
+
+        _native.wgrad_flush = spy
+        step(partial, gt)
+        _native.wgrad_flush = flush
+        torch.cuda.synchronize()
+        print(f"fused k/v projection {fused}: grouped launches per step (problems, GFLOP): {[(n, round(g, 1)) for n, g in sizes]}")
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                step(partial, gt)
+            torch.cuda.synchronize()
+        rows = {e.key: (e.count / 3, e.self_device_time_total / 3e3) for e in prof.key_averages()}
+        for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:14]:
+            print(f"     {t:8.3f} ms  x{c:6.1f}  {k[:100]}")
+        print(f"     total kernel time {sum(t for _, t in rows.values()):.3f} ms, {sum(c for c, _ in rows.values()):.0f} launches")
+    TU.FUSED_KV_PROJECTION = True
+
+
+if __name__ == "__main__":
+    main()

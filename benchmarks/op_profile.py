@@ -31,7 +31,12 @@ def main():
         step(partial, gt)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    try:
+        xcfg = torch._C._profiler._ExperimentalConfig(verbose=True)       # python stacks in key_averages(group_by_stack_n)
+    except Exception:
+        xcfg = None
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True,
+                 experimental_config=xcfg) as prof:
         for _ in range(3):
             step(partial, gt)
         torch.cuda.synchronize()
@@ -48,16 +53,17 @@ def main():
     # the same small ops by CALL SITE (innermost frame inside this package), launches and device time per step
     import collections
     site = collections.defaultdict(lambda: [0, 0.0])
-    for e in prof.key_averages(group_by_stack_n=12):
+    for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
         if not (e.key.startswith("aten::") and e.key not in skip and getattr(e, "self_device_time_total", 0) > 0):
             continue
         frames = [f for f in (e.stack or []) if "imgadapointr_amd" in f or "bench.py" in f]
-        where = frames[0].split("imgadapointr_amd/")[-1] if frames else "(torch internals / autograd)"
-        site[(e.key, where)][0] += e.count
-        site[(e.key, where)][1] += e.self_device_time_total
+        where = " <- ".join(f.split("imgadapointr_amd/")[-1].strip() for f in frames[:2]) if frames else "(autograd engine: backward of a torch op)"
+        shp = str([x for x in e.input_shapes if x])[:60] if where.startswith("tools/runner.py") or where.startswith("(autograd") else ""
+        site[(e.key + " " + shp, where)][0] += e.count
+        site[(e.key + " " + shp, where)][1] += e.self_device_time_total
     print("\nnon-GEMM aten ops by call site (launch-count order)")
-    for (op, where), (cnt, t) in sorted(site.items(), key=lambda kv: -kv[1][0])[:70]:
-        print(f"  x{cnt / 3:6.1f} {t / 3e3:8.3f} ms  {op:34s} {where[:110]}")
+    for (op, where), (cnt, t) in sorted(site.items(), key=lambda kv: -kv[1][0])[:110]:
+        print(f"  x{cnt / 3:6.1f} {t / 3e3:8.3f} ms  {op:74s} {where[:110]}")
     # the library GEMMs by shape (which dense layers still run on hipBLASLt / rocBLAS)
     rows = [e for e in prof.key_averages(group_by_input_shape=True)
             if e.key in ("aten::mm", "aten::addmm", "aten::bmm") and getattr(e, "self_device_time_total", 0) > 0]

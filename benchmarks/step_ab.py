@@ -42,7 +42,8 @@ def main():
             ("Chamfer backward with atomics (reference form)", attr(_native, "DETERMINISTIC_BACKWARD", False)),
             ("forward GEMM at three workgroups per CU", opt("PTOPS_GEMM_OCC3", 1)),
             ("attention without the XCD job order", opt("PTOPS_ATTN_NO_XCD_REMAP", 1)),
-            ("immediate folds", attr(runner, "DEFER_FOLDS", False)),
+            ("immediate folds (and weight gradients)", attr(runner, "DEFER_FOLDS", False)),
+            ("weight gradients per layer, not grouped", attr(_native, "GROUPED_WGRAD", False)),
             ("k_map and v_map as two projections", attr(TU, "FUSED_KV_PROJECTION", False)),
             ("Chamfer MFMA with fragment prefetch", opt("PTOPS_CHAMFER_MFMA_PREFETCH", 1))]
     for _ in range(8):

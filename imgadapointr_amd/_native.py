@@ -76,6 +76,10 @@ def _declare(lib):
         "ptops_gemm_f32_split3_wgrad_workspace": (ctypes.c_longlong, [c_int, c_int, c_int]),
         "ptops_gemm_f32_split3_wgrad": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, c_int, c_int, c_int, P,
                                                 ctypes.c_longlong, P, P, ctypes.c_longlong, P]),
+        "ptops_wgrad_problem_bytes": (c_int, []),
+        "ptops_wgrad_group_plan": (ctypes.c_longlong, [P, P, c_int, c_int, P, ctypes.c_longlong]),
+        "ptops_wgrad_group_workspace_bytes": (ctypes.c_longlong, [P]),
+        "ptops_gemm_f32_split3_wgrad_grouped": (c_int, [P, P, c_int, P, P, P, ctypes.c_longlong, P]),
         "ptops_max_tokens_backward": (c_int, [P, P, c_int, c_int, c_int, P, P]),
         "ptops_attention_forward": (c_int, [P, P, P] + [c_int] * 4 + [P, P, P, c_int, c_int, ctypes.c_float, P, P, P]),
         "ptops_layer_norm_max_dim": (c_int, []),
@@ -112,6 +116,8 @@ EXPORTS = (
     "ptops_fold_defer", "ptops_fold_flush", "ptops_set_option", "ptops_get_option", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
     "ptops_max_tokens_forward", "ptops_max_tokens_backward", "ptops_gemm_f32_split3",
     "ptops_gemm_f32_split3_wgrad_workspace", "ptops_gemm_f32_split3_wgrad", "ptops_gemm_f32_split3_gelu",
+    "ptops_wgrad_problem_bytes", "ptops_wgrad_group_plan", "ptops_wgrad_group_workspace_bytes",
+    "ptops_gemm_f32_split3_wgrad_grouped",
     "ptops_edge_select_blocks", "ptops_edge_select", "ptops_edge_scatter",
     "ptops_edge_norm_forward", "ptops_edge_norm_backward_workspace_bytes", "ptops_edge_norm_backward",
     "ptops_batch_norm_rows_workspace_bytes", "ptops_batch_norm_rows_forward", "ptops_batch_norm_rows_backward",
@@ -681,7 +687,8 @@ def fold_returning(key):
 
 
 def fold_flush():
-    """Runs the queued folds on the stream they were queued on (no-op when nothing is queued)."""
+    """Runs the queued weight gradients and folds on the stream they were queued on (no-op when nothing is queued)."""
+    wgrad_flush()
     if _fold_keepalive:
         dev = _fold_keepalive[0].device
         with torch.cuda.device(dev):
@@ -823,6 +830,83 @@ def gemm_split3_wgrad(dy, x, want_bias=False):
         _call("ptops_gemm_f32_split3_wgrad", _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dw), dw.stride(0),
               _ptr(db) if db is not None else None, _ptr(ws), need, _stream(dy))
     return dw, db
+
+
+# ---- grouped weight gradients (include/ptops.h): queued during backward, two launches at the flush ------------------
+GROUPED_WGRAD = os.environ.get("PTOPS_GROUPED_WGRAD", "1") != "0"
+_wgrad_queue = []             # (dy, x, dW pointer, db pointer or 0, M, N, K): operands alive until the flush
+_wgrad_plans = {}             # (device index, shapes) -> (host plan bytes, device plan, workspace bytes)
+_wgrad_ws = {}                # device index -> workspace tensor
+
+
+def wgrad_deferrable(dy, x):
+    """True while `deferred_folds` is active: dy^T.x (and the column sums of dy) may be queued with `wgrad_defer`."""
+    return (GROUPED_WGRAD and _fold_deferred and _test_backend is None and dy.is_cuda and dy.dtype == torch.float32
+            and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1
+            and dy.size(0) == x.size(0) and dy.size(0) >= 16 and dy.size(0) % 16 == 0 and x.size(1) % 4 == 0
+            and dy.device == _fold_stream[0] and torch.cuda.current_stream(dy.device).cuda_stream == (_fold_stream[1].value or 0))
+
+
+def wgrad_defer(dy, x, want_bias):
+    """Queues dW = dy^T.x [N,K] (and db = column sums of dy when `want_bias`, N % 4 == 0) for the grouped launch of the
+    next `fold_flush()`; -> (dW, db) whose values exist only after that flush (same contract as a deferred fold: the
+    caller hands them to autograd as the FIRST gradient of a leaf and announces that with `fold_returning`)."""
+    M, N = dy.shape
+    K = x.size(1)
+    dev = dy.device
+    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev) if want_bias else None
+    if FOLD_POISON:
+        dw.fill_(float("nan"))
+        if db is not None:
+            db.fill_(float("nan"))
+    # the outputs' storage must outlive the queue even if autograd drops them; holding the tensor itself would make
+    # AccumulateGrad clone (= read) instead of adopting it
+    _wgrad_queue.append((dy, x, dw.data_ptr(), db.data_ptr() if db is not None else 0, M, N, K, dw.untyped_storage(),
+                         db.untyped_storage() if db is not None else None))
+    return dw, db
+
+
+def wgrad_flush():
+    """Runs every queued weight gradient in one grouped launch (csrc/gemm_split3.hip) on the deferral stream."""
+    if not _wgrad_queue:
+        return
+    import numpy as np
+    queue = list(_wgrad_queue)
+    _wgrad_queue.clear()
+    dev = queue[0][0].device
+    n = len(queue)
+    lib = load()
+    with torch.cuda.device(dev):
+        handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev.index, tuple((q[4], q[5], q[6], q[3] != 0) for q in queue))
+        plan = _wgrad_plans.get(key)
+        if plan is None:
+            mnk = np.ascontiguousarray([[q[4], q[5], q[6]] for q in queue], dtype=np.int32)
+            flags = np.ascontiguousarray([1 if q[3] else 0 for q in queue], dtype=np.uint8)
+            need = int(lib.ptops_wgrad_group_plan(mnk.ctypes.data, flags.ctypes.data, n, 0, None, 0))
+            if need <= 0:
+                raise PtopsError("wgrad_flush: unsupported problem in the queue")
+            host = np.zeros(need, dtype=np.uint8)
+            lib.ptops_wgrad_group_plan(mnk.ctypes.data, flags.ctypes.data, n, 0, host.ctypes.data, need)
+            plan = (host, torch.from_numpy(host).to(dev), int(lib.ptops_wgrad_group_workspace_bytes(host.ctypes.data)))
+            if len(_wgrad_plans) > 16:
+                _wgrad_plans.clear()
+            _wgrad_plans[key] = plan
+        host_plan, dev_plan, ws_bytes = plan
+        ws = _wgrad_ws.get(dev.index)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _wgrad_ws[dev.index] = ws
+        rows = np.zeros((n, 9), dtype=np.int64)                 # PtopsWgradProblem: 4 pointers, 3 strides, 4 int32
+        assert lib.ptops_wgrad_problem_bytes() == 72
+        for i, (dy, x, pw, pb, M, N, K, _sw, _sb) in enumerate(queue):
+            rows[i] = (dy.data_ptr(), x.data_ptr(), pw, pb, dy.stride(0), x.stride(0), K, M | (N << 32), K)
+        pinned = torch.from_numpy(rows).pin_memory()
+        rows_dev = pinned.to(dev, non_blocking=True)
+        _call("ptops_gemm_f32_split3_wgrad_grouped", ctypes.c_void_p(rows.ctypes.data), _ptr(rows_dev), n,
+              ctypes.c_void_p(host_plan.ctypes.data), _ptr(dev_plan), _ptr(ws), ws.numel(), handle)
+        # `queue` (operands, output storages) and rows_dev die here: the launches are queued behind them in stream order
 
 
 def adamw_clip_step(rows_dev, n_tensors, chunks_dev, n_chunks, max_norm, beta1, beta2, eps, partial, norm_coef):

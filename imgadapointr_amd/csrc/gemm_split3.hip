@@ -15,6 +15,11 @@
 // the current one computes; double-buffered LDS, one barrier per k-step.  Either operand may be stored with k
 // contiguous ([rows, ld]) or with k strided ([K, ld], rows contiguous): the strided form reads 8 coalesced dwords
 // instead of two dwordx4, so A.B^T (forward), A.B (input gradient) and A^T.B (weight gradient) use one kernel.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "ptops_common.h"
 
 namespace {
@@ -205,21 +210,19 @@ struct WgradArgs {
   int steps_per_split;
 };
 
-__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) {
-  __shared__ uint4 lds[2][2][3][2 * kPlane];
-  __shared__ float sB[256];
-
+// One 128 x 128 tile of dY^T . X over the k-steps [ks_begin, ks_end) (16 rows of the contraction each): the product goes
+// to part[N][K], the column sums of the dY rows it staged to bpart[N] (when not null; the caller passes it to ONE of the
+// tiles that share these dY columns).
+__device__ __forceinline__ void wgrad_tile(const float* __restrict__ dY, const float* __restrict__ X, long long ldy,
+                                           long long ldx, int N, int K, int n0, int c0, int ks_begin, int ks_end,
+                                           float* __restrict__ part, float* __restrict__ bpart,
+                                           uint4 (&lds)[2][2][3][2 * kPlane], float (&sB)[256]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int col = lane & 31, half = lane >> 5;
-  const int bid = blockIdx.x, split = blockIdx.y;
-  const int tile_n = bid / g.tiles_k, tile_k = bid - tile_n * g.tiles_k;
-  const int n0 = tile_n * kBM, c0 = tile_k * kBN;              // output rows (N) / columns (K)
   const bool stage_b = t >= 256;
   const int tt = t & 255;
   const int e = entry_index<false>(tt);
-  const int ks_total = g.M / kBK;
-  const int ks_begin = split * g.steps_per_split, ks_end = min(ks_begin + g.steps_per_split, ks_total);
 
   f32x16 acc[2];
 #pragma unroll
@@ -228,13 +231,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) 
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   float x[8];
-  float bsum = 0.f;                                            // A stagers: sum of this thread's dY entries
+  // A stagers: sum of this thread's dY entries, in two levels (16 k-steps go to `blo`, which is then added to `bhi`):
+  // a job stages up to a few thousand rows, and one running sum would carry that many roundings
+  float blo = 0.f, bhi = 0.f;
+  int bcount = 0;
   auto load = [&](int ks) {
-    if (stage_b) load_entry<false>(g.X, g.ldx, g.K, c0, ks * kBK, tt, x);
-    else load_entry<false>(g.dY, g.ldy, g.N, n0, ks * kBK, tt, x);
+    if (stage_b) load_entry<false>(X, ldx, K, c0, ks * kBK, tt, x);
+    else load_entry<false>(dY, ldy, N, n0, ks * kBK, tt, x);
   };
   auto store = [&](int buf) {
-    bsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    blo += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    if (++bcount == 16) bhi += blo, blo = 0.f, bcount = 0;
     const Pieces p = split8(x);
     uint4(*dst)[2 * kPlane] = lds[buf][stage_b ? 1 : 0];
     dst[0][e] = p.h, dst[1][e] = p.m, dst[2][e] = p.l;
@@ -266,21 +273,107 @@ __global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) 
     __syncthreads();
   }
 
-  float* part = g.part + (long long)split * g.N * g.K;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = c0 + wc * 64 + j * 32 + col;
-    if (c >= g.K) continue;
+    if (c >= K) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n < g.N) part[(long long)n * g.K + c] = acc[j][r];
+      if (n < N) part[(long long)n * K + c] = acc[j][r];
     }
   }
-  if (g.bpart && tile_k == 0) {                                // every tile_k sees the same dY rows: one of them reports
-    if (!stage_b) sB[tt] = bsum;                               // entry tt: row tt & 127, k-half tt >> 7
+  if (bpart) {                                                 // uniform per workgroup
+    if (!stage_b) sB[tt] = bhi + blo;                          // entry tt: row tt & 127, k-half tt >> 7
     __syncthreads();
-    if (t < 128 && n0 + t < g.N) g.bpart[(long long)split * g.N + n0 + t] = sB[t] + sB[t + 128];
+    if (t < 128 && n0 + t < N) bpart[n0 + t] = sB[t] + sB[t + 128];
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_kernel(WgradArgs g) {
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+  __shared__ float sB[256];
+  const int bid = blockIdx.x, split = blockIdx.y;
+  const int tile_n = bid / g.tiles_k, tile_k = bid - tile_n * g.tiles_k;
+  const int ks_total = g.M / kBK;
+  const int ks_begin = split * g.steps_per_split, ks_end = min(ks_begin + g.steps_per_split, ks_total);
+  // every tile_k sees the same dY rows: one of them reports the column sums
+  wgrad_tile(g.dY, g.X, g.ldy, g.ldx, g.N, g.K, tile_n * kBM, tile_k * kBN, ks_begin, ks_end,
+             g.part + (long long)split * g.N * g.K,
+             (g.bpart && tile_k == 0) ? g.bpart + (long long)split * g.N : nullptr, lds, sB);
+}
+
+// ---- grouped weight gradients: the dW (and db) of MANY layers in one launch ------------------------------------------
+// A 384 x 384 layer has 9 output tiles: on its own it needs a 50-fold split of the contraction to fill 256 CUs, and the
+// 9 tiles that share its operand columns land on 8 different XCDs (8 L2s), so each operand is fetched from HBM three
+// times.  The layers' weight gradients do not depend on each other, so the host queues them during the backward pass and
+// one launch runs them all: a job = (layer, contraction split, tile); the planner gives every (layer, split) group of
+// tiles to ONE XCD (workgroup b runs on XCD b % 8; the job table is laid out for that) so the operand slabs are shared
+// through that XCD's L2, balances the XCD queues by work, and keeps the splits few (long steady-state loops, little
+// partial traffic).  A second launch adds the partials of all layers in a fixed order (deterministic, no atomics).
+struct WgradProblem {     // == PtopsWgradProblem (include/ptops.h), 72 bytes
+  const float* dY;
+  const float* X;
+  float* dW;
+  float* db;              // or null
+  long long ldy, ldx, lddw;
+  int M, N, K, pad;
+};
+struct WgradPlanHeader {  // 32 bytes
+  int magic, n_problems, n_jobs, n_rjobs;
+  long long workspace_bytes, reserved;
+};
+struct WgradPlanProblem { // 32 bytes; bases in floats from the workspace start
+  long long part_base, bpart_base;
+  int splits, steps_per_split, tiles_k, pad;
+};
+struct WgradJob {         // 16 bytes; problem < 0: padding of a shorter XCD queue
+  int problem, tile, split, pad;
+};
+struct WgradRJob {        // 16 bytes: 1024-float chunk `chunk` of dW (kind 0) or db (kind 1) of a problem
+  int problem, kind, chunk, pad;
+};
+constexpr int kWgradMagic = 0x57475233;
+
+__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_grouped_kernel(const WgradProblem* __restrict__ probs,
+                                                                           const WgradPlanProblem* __restrict__ plan,
+                                                                           const WgradJob* __restrict__ jobs,
+                                                                           float* __restrict__ ws) {
+  __shared__ uint4 lds[2][2][3][2 * kPlane];
+  __shared__ float sB[256];
+  const WgradJob job = jobs[blockIdx.x];
+  if (job.problem < 0) return;
+  const WgradProblem P = probs[job.problem];
+  const WgradPlanProblem Q = plan[job.problem];
+  const int tile_n = job.tile / Q.tiles_k, tile_k = job.tile - tile_n * Q.tiles_k;
+  const int ks_begin = job.split * Q.steps_per_split, ks_end = min(ks_begin + Q.steps_per_split, P.M / kBK);
+  wgrad_tile(P.dY, P.X, P.ldy, P.ldx, P.N, P.K, tile_n * kBM, tile_k * kBN, ks_begin, ks_end,
+             ws + Q.part_base + (long long)job.split * P.N * P.K,
+             (P.db && tile_k == 0) ? ws + Q.bpart_base + (long long)job.split * P.N : nullptr, lds, sB);
+}
+
+__global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(const WgradProblem* __restrict__ probs,
+                                                                   const WgradPlanProblem* __restrict__ plan,
+                                                                   const WgradRJob* __restrict__ rjobs,
+                                                                   const float* __restrict__ ws) {
+  const WgradRJob rj = rjobs[blockIdx.x];
+  const WgradProblem P = probs[rj.problem];
+  const WgradPlanProblem Q = plan[rj.problem];
+  const long long count = rj.kind == 0 ? (long long)P.N * P.K : (long long)P.N;
+  const long long i = (long long)rj.chunk * 1024 + threadIdx.x * 4;
+  if (i >= count) return;
+  const float* part = ws + (rj.kind == 0 ? Q.part_base : Q.bpart_base);
+  float4 s = *reinterpret_cast<const float4*>(part + i);
+  for (int k = 1; k < Q.splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (long long)k * count + i);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  if (rj.kind == 0) {
+    const long long row = i / P.K;
+    const int c = (int)(i - row * P.K);
+    *reinterpret_cast<float4*>(P.dW + row * P.lddw + c) = s;
+  } else {
+    *reinterpret_cast<float4*>(P.db + i) = s;
   }
 }
 
@@ -398,4 +491,150 @@ PTOPS_API int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ptops::ceil_div_ll(N, 1024)), dim3(256), 0, stream, g.bpart,
                      (long long)N, splits, db, (long long)N, N);
   return ptops::check_launch("wgrad_reduce_kernel");
+}
+
+// ---- grouped weight gradients: planner + launch ---------------------------------------------------------------------
+namespace {
+
+struct WgradGroup {          // the tiles of one (problem, split): one XCD runs them all
+  int problem, split, tiles;
+  long long cost;            // tiles x k-steps
+};
+
+int wgrad_group_target_steps(int steps_target) {
+  if (steps_target > 0) return steps_target;
+  const int opt = ptops::option("PTOPS_WGRAD_GROUP_STEPS");
+  return opt > 0 ? opt : 288;
+}
+
+// splits / steps per split of one problem for a target job length
+void wgrad_group_split(int M, int target, int* splits, int* per) {
+  const int ksteps = M / kBK;
+  int s = (ksteps + target / 2) / target;
+  s = s < 1 ? 1 : s;
+  *per = ptops::ceil_div(ksteps, s);
+  *splits = ptops::ceil_div(ksteps, *per);
+}
+
+}  // namespace
+
+// Plans the grouped launch for n problems given as {M, N, K} triples (want_db[i] != 0: problem i also delivers db).
+// Returns the size of the plan in bytes; writes it when `plan` holds at least that many (same bytes go to the device).
+// The plan depends on the shapes only: a training loop builds it once.
+PTOPS_API long long ptops_wgrad_group_plan(const int* mnk, const unsigned char* want_db, int n, int steps_target, void* plan,
+                                           long long capacity) {
+  if (!mnk || n <= 0) return 0;
+  const int target = wgrad_group_target_steps(steps_target);
+  std::vector<WgradPlanProblem> pp((size_t)n);
+  std::vector<WgradGroup> groups;
+  long long ws_floats = 0, n_rjobs = 0;
+  for (int i = 0; i < n; ++i) {
+    const int M = mnk[3 * i], N = mnk[3 * i + 1], K = mnk[3 * i + 2];
+    if (M < kBK || M % kBK || N < 1 || K < 1 || K % 4) return -1;
+    if (want_db && want_db[i] && N % 4) return -1;
+    int splits, per;
+    wgrad_group_split(M, target, &splits, &per);
+    WgradPlanProblem& q = pp[(size_t)i];
+    q.splits = splits, q.steps_per_split = per, q.tiles_k = ptops::ceil_div(K, kBN), q.pad = 0;
+    q.part_base = ws_floats;
+    ws_floats += (long long)splits * N * K;
+    q.bpart_base = ws_floats;
+    if (want_db && want_db[i]) ws_floats += ((long long)splits * N + 3) / 4 * 4;
+    const int tiles = ptops::ceil_div(N, kBM) * q.tiles_k;
+    const int ksteps = M / kBK;
+    for (int s = 0; s < splits; ++s) {
+      const int len = std::min(per, ksteps - s * per);
+      groups.push_back({i, s, tiles, (long long)tiles * len});
+    }
+    n_rjobs += ptops::ceil_div_ll((long long)N * K, 1024) + ((want_db && want_db[i]) ? ptops::ceil_div(N, 1024) : 0);
+  }
+  // longest groups first, each to the XCD queue with the least work so far
+  std::stable_sort(groups.begin(), groups.end(), [](const WgradGroup& a, const WgradGroup& b) { return a.cost > b.cost; });
+  std::vector<WgradJob> queue[8];
+  long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (const WgradGroup& g : groups) {
+    int x = 0;
+    for (int j = 1; j < 8; ++j)
+      if (load[j] < load[x]) x = j;
+    load[x] += g.cost;
+    for (int t = 0; t < g.tiles; ++t) queue[x].push_back({g.problem, t, g.split, 0});
+  }
+  size_t rounds = 0;
+  for (int x = 0; x < 8; ++x) rounds = std::max(rounds, queue[x].size());
+  const long long n_jobs = (long long)rounds * 8;
+  const long long bytes = (long long)sizeof(WgradPlanHeader) + (long long)n * sizeof(WgradPlanProblem) +
+                          n_jobs * (long long)sizeof(WgradJob) + n_rjobs * (long long)sizeof(WgradRJob);
+  if (!plan || capacity < bytes) return bytes;
+  if (n_jobs >= (1LL << 31) || n_rjobs >= (1LL << 31)) return -1;
+  unsigned char* out = (unsigned char*)plan;
+  WgradPlanHeader h;
+  h.magic = kWgradMagic, h.n_problems = n, h.n_jobs = (int)n_jobs, h.n_rjobs = (int)n_rjobs;
+  h.workspace_bytes = std::max<long long>(ws_floats, 4) * (long long)sizeof(float), h.reserved = target;
+  memcpy(out, &h, sizeof h);
+  out += sizeof h;
+  memcpy(out, pp.data(), (size_t)n * sizeof(WgradPlanProblem));
+  out += (size_t)n * sizeof(WgradPlanProblem);
+  WgradJob* jobs = (WgradJob*)out;
+  for (size_t r = 0; r < rounds; ++r)
+    for (int x = 0; x < 8; ++x) jobs[r * 8 + x] = r < queue[x].size() ? queue[x][r] : WgradJob{-1, 0, 0, 0};
+  out += (size_t)n_jobs * sizeof(WgradJob);
+  WgradRJob* rj = (WgradRJob*)out;
+  for (int i = 0; i < n; ++i) {
+    const int N = mnk[3 * i + 1], K = mnk[3 * i + 2];
+    const int chunks = (int)ptops::ceil_div_ll((long long)N * K, 1024);
+    for (int c = 0; c < chunks; ++c) *rj++ = {i, 0, c, 0};
+    if (want_db && want_db[i])
+      for (int c = 0; c < ptops::ceil_div(N, 1024); ++c) *rj++ = {i, 1, c, 0};
+  }
+  return bytes;
+}
+
+PTOPS_API long long ptops_wgrad_group_workspace_bytes(const void* plan_host) {
+  if (!plan_host) return 0;
+  WgradPlanHeader h;
+  memcpy(&h, plan_host, sizeof h);
+  return h.magic == kWgradMagic ? h.workspace_bytes : -1;
+}
+
+PTOPS_API int ptops_wgrad_problem_bytes(void) { return (int)sizeof(WgradProblem); }
+
+// Runs the plan.  problems_host / problems_dev: the same n rows of PtopsWgradProblem (the host copy is only validated
+// against the plan); plan_host / plan_dev: the bytes ptops_wgrad_group_plan wrote; workspace: device scratch of
+// ptops_wgrad_group_workspace_bytes(plan_host), 16-byte aligned.  Two launches, whatever n is.
+PTOPS_API int ptops_gemm_f32_split3_wgrad_grouped(const void* problems_host, const void* problems_dev, int n,
+                                                  const void* plan_host, const void* plan_dev, void* workspace,
+                                                  long long workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(problems_host && problems_dev && plan_host && plan_dev && workspace, "wgrad_grouped: null pointer");
+  WgradPlanHeader h;
+  memcpy(&h, plan_host, sizeof h);
+  PTOPS_REQUIRE(h.magic == kWgradMagic && h.n_problems == n, "wgrad_grouped: the plan is not for these %d problems", n);
+  PTOPS_REQUIRE(workspace_bytes >= h.workspace_bytes && ((uintptr_t)workspace & 15) == 0, "wgrad_grouped: workspace too small or misaligned");
+  const WgradPlanProblem* qh = (const WgradPlanProblem*)((const unsigned char*)plan_host + sizeof h);
+  const WgradProblem* ph = (const WgradProblem*)problems_host;
+  for (int i = 0; i < n; ++i) {
+    const WgradProblem& p = ph[i];
+    PTOPS_REQUIRE(p.dY && p.X && p.dW, "wgrad_grouped: null operand in problem %d", i);
+    PTOPS_REQUIRE(p.M >= kBK && p.M % kBK == 0 && p.K % 4 == 0 && p.lddw % 4 == 0 && ((uintptr_t)p.dW & 15) == 0,
+                  "wgrad_grouped: problem %d: M %% 16, K %% 4, 16-byte aligned dW rows required", i);
+    PTOPS_REQUIRE(!p.db || (p.N % 4 == 0 && ((uintptr_t)p.db & 15) == 0), "wgrad_grouped: problem %d: db needs N %% 4 == 0 and 16-byte alignment", i);
+    int splits, per;
+    wgrad_group_split(p.M, (int)h.reserved, &splits, &per);
+    PTOPS_REQUIRE(splits == qh[i].splits && per == qh[i].steps_per_split && ptops::ceil_div(p.K, kBN) == qh[i].tiles_k,
+                  "wgrad_grouped: problem %d does not match the plan", i);
+    const long long room = (i + 1 < n ? qh[i + 1].part_base : h.workspace_bytes / (long long)sizeof(float)) - qh[i].part_base;
+    PTOPS_REQUIRE(room >= (long long)splits * p.N * p.K + (p.db ? (long long)splits * p.N : 0), "wgrad_grouped: problem %d does not match the plan", i);
+  }
+  const unsigned char* pd = (const unsigned char*)plan_dev + sizeof h;
+  const WgradPlanProblem* qd = (const WgradPlanProblem*)pd;
+  const WgradJob* jobs = (const WgradJob*)(pd + (size_t)n * sizeof(WgradPlanProblem));
+  const WgradRJob* rjobs = (const WgradRJob*)((const unsigned char*)jobs + (size_t)h.n_jobs * sizeof(WgradJob));
+  hipLaunchKernelGGL(gemm_split3_wgrad_grouped_kernel, dim3((unsigned)h.n_jobs), dim3(512), 0, stream,
+                     (const WgradProblem*)problems_dev, qd, jobs, (float*)workspace);
+  int rc = ptops::check_launch("gemm_split3_wgrad_grouped_kernel");
+  if (rc != PTOPS_OK) return rc;
+  hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3((unsigned)h.n_rjobs), dim3(256), 0, stream,
+                     (const WgradProblem*)problems_dev, qd, rjobs, (const float*)workspace);
+  return ptops::check_launch("wgrad_grouped_reduce_kernel");
 }

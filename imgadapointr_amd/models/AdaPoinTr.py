@@ -57,8 +57,8 @@ def _linear_tokens(x, weight, bias):
     if (x.is_cuda and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
             and _native.backend_for_testing() is None and x.size(0) >= 2048):
         return _LinearFn.apply(x, weight, bias)
-    if bias is not None and torch.is_grad_enabled():
-        _native.fold_mark_plain(bias.data_ptr())                 # plain autograd path: see _native.deferred_folds
+    if torch.is_grad_enabled():                                  # plain autograd path: see _native.deferred_folds
+        _native.fold_mark_plain(("weight", weight.data_ptr()), bias.data_ptr() if bias is not None else None)
     return torch.nn.functional.linear(x, weight, bias)
 
 

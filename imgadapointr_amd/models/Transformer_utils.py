@@ -58,8 +58,8 @@ def linear_on_broadcast_concat(lin, g, x):
     if not SPLIT_BROADCAST_LINEAR:
         return lin(torch.cat([g.unsqueeze(1).expand(-1, x.size(1), -1), x], dim=-1))
     G = g.size(-1)
-    if lin.bias is not None and torch.is_grad_enabled():
-        _native.fold_mark_plain(lin.bias.data_ptr())            # plain autograd path: see _native.deferred_folds
+    if torch.is_grad_enabled():                                 # plain autograd path: see _native.deferred_folds
+        _native.fold_mark_plain(("weight", lin.weight.data_ptr()), lin.bias.data_ptr() if lin.bias is not None else None)
     per_cloud = F.linear(g, lin.weight[:, :G], lin.bias)        # [B,O]
     return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
 
@@ -143,7 +143,13 @@ def _linear_backward(ctx, x, weight, grad, gb):
             gx = (g2 @ weight).view(x.shape)
     if ctx.needs_input_grad[1]:
         x2 = x.reshape(-1, x.size(-1))
-        if _use_split3_wgrad(g2, x2):
+        if USE_SPLIT3_WGRAD and _native.wgrad_deferrable(g2, x2):
+            # nothing reads a weight gradient before the end of backward: queue it for the grouped launch
+            # (_native.wgrad_defer: all layers in two launches, tiles of a layer on one XCD, bias gradient included)
+            gw, db = _native.wgrad_defer(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
+            gb = db if db is not None else gb
+            _native.fold_returning(("weight", weight.data_ptr()))
+        elif _use_split3_wgrad(g2, x2):
             # the bias gradient (column sums of g2) falls out of the same pass
             gw, db = _native.gemm_split3_wgrad(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
             gb = db if db is not None else gb
@@ -233,8 +239,8 @@ class Linear(nn.Linear):
             return _LinearFn.apply(x, self.weight, self.bias)
         if not torch.is_grad_enabled():
             return linear_forward(x, self.weight, self.bias)      # validation / inference: same kernels as training
-        if self.bias is not None:
-            _native.fold_mark_plain(self.bias.data_ptr())         # plain autograd path: see _native.deferred_folds
+        # plain autograd path: see _native.deferred_folds
+        _native.fold_mark_plain(("weight", self.weight.data_ptr()), self.bias.data_ptr() if self.bias is not None else None)
         return F.linear(x, self.weight, self.bias)
 
 
@@ -671,8 +677,9 @@ class CrossAttention(nn.Module):
                 and (self.attn_drop.p == 0.0 or not self.training) and N % 32 == 0 and NK % 32 == 0):
             wkv = torch.cat([self.k_map.weight, self.v_map.weight], dim=0)            # [2C, C]: 1.2 MB, once per call
             bkv = torch.cat([self.k_map.bias, self.v_map.bias], dim=0)
-            # the bias gradient travels on through cat's backward as two views: not a gradient autograd adopts unread
-            _native.fold_mark_plain(bkv.data_ptr())
+            # the weight / bias gradients travel on through cat's backward as two dim-0 views each, which AccumulateGrad
+            # adopts without reading (dense, strides of the parameter, sole owner): they may stay queued (deferred
+            # folds / grouped weight gradients; test_cross_attention_fused_kv_projection runs this with poisoned outputs)
             kv = _LinearFn.apply(k.reshape(B * NK, -1), wkv, bkv).view(B, NK, 2, h, C // h)
             x = _MFMAKVAttention.apply(q, kv, self.scale).reshape(B, N, C)
             return self.proj_drop(self.proj(x))

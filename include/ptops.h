@@ -364,6 +364,32 @@ int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, 
                                 float* dW, long long lddw, float* db, void* workspace, long long workspace_bytes,
                                 void* stream);
 
+/* The weight (and bias) gradients of MANY layers in two launches.  A layer's dW has few output tiles and a long
+ * contraction, and nothing in a backward pass reads it before the optimizer: the host side queues the (dY, X) pairs
+ * while autograd runs (torch's Linear backward, models/Transformer_utils.py:71-159 of the reference, computes each
+ * dY^T.X at once) and runs them together.  Per problem the arithmetic and the fixed-order reduction are those of
+ * ptops_gemm_f32_split3_wgrad; the planner gives all tiles of a (problem, contraction split) to one XCD.
+ *   problems: n rows of PtopsWgradProblem, the same bytes on the host (validated) and on the device (read by the kernels);
+ *   plan:     ptops_wgrad_group_plan(mnk = n x {M,N,K}, want_db = n flags or NULL, steps_target = 0 for the default
+ *             job length in 16-row steps, plan, capacity) returns the plan's size in bytes (-1: unsupported shape) and
+ *             writes it when capacity suffices; it depends on the shapes only, the caller copies it to the device once;
+ *   workspace: ptops_wgrad_group_workspace_bytes(plan) bytes of device scratch, 16-byte aligned.
+ * M % 16 == 0, K % 4 == 0, dW rows 16-byte aligned; with db: N % 4 == 0, db 16-byte aligned. */
+typedef struct PtopsWgradProblem {
+  const float* dY;          /* [M, ldy] */
+  const float* X;           /* [M, ldx] */
+  float* dW;                /* [N, lddw] out */
+  float* db;                /* [N] out, or NULL */
+  long long ldy, ldx, lddw;
+  int M, N, K, reserved;
+} PtopsWgradProblem;
+int ptops_wgrad_problem_bytes(void);                    /* sizeof(PtopsWgradProblem) = 72 */
+long long ptops_wgrad_group_plan(const int* mnk, const unsigned char* want_db, int n, int steps_target, void* plan,
+                                 long long capacity);
+long long ptops_wgrad_group_workspace_bytes(const void* plan_host);
+int ptops_gemm_f32_split3_wgrad_grouped(const void* problems_host, const void* problems_dev, int n, const void* plan_host,
+                                        const void* plan_dev, void* workspace, long long workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------- clip + AdamW --
  * torch.nn.utils.clip_grad_norm_(params, max_norm, 2) followed by torch.optim.AdamW.step() (tools/runner.py:208-212,
  * tools/builder.py:37-52) for ALL parameters in three launches: |g|^2 per 4096-element chunk, the norm and the clip

@@ -531,7 +531,10 @@ def check_trainstep(case, device):
     compare_ranked(ret[0].detach().cpu().numpy(), ret[3][:, :2048].detach().cpu().numpy(), g["pred_coarse"],
                    g["pred_fine_head"], tol)
     d_loss = (abs(l_den.item() - float(g["loss_denoised"])) * 1000, abs(l_rec.item() - float(g["loss_recon"])) * 1000)
-    assert max(d_loss) < 1e-3, d_loss
+    # losses x 1000 (the logged unit).  The seg case's frozen GDANet runs on MIOpen / rocBLAS kernels the library picks at
+    # run time: its forward differs at rounding level from box to box (1.3e-3 seen), on top of the conditioning measured by
+    # benchmarks/trainstep_spread.py
+    assert max(d_loss) < (4e-3 if case == "seg" else 1e-3), d_loss
     no_grad = sorted(n for n, p in named.items() if p.requires_grad and n not in grads)
     assert no_grad == mt["no_grad_params"], (no_grad, mt["no_grad_params"])
     assert not any(n in grads for n, p in named.items() if not p.requires_grad)
