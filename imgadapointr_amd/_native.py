@@ -40,6 +40,9 @@ def _declare(lib):
         "ptops_chamfer_backward": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P]),
         "ptops_chamfer_backward_det_workspace_bytes": (c_size, [c_int] * 3),
         "ptops_chamfer_backward_det": (c_int, [P] * 6 + [c_int] * 3 + [P, P, P, c_size, P]),
+        "ptops_chamfer_reduce_workspace_bytes": (c_size, [ctypes.c_longlong, ctypes.c_longlong]),
+        "ptops_chamfer_reduce": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, c_int, P, P, P]),
+        "ptops_chamfer_reduce_backward": (c_int, [P, ctypes.c_longlong, P, ctypes.c_longlong, c_int, c_int, P, P, P, P, P]),
         "ptops_furthest_point_sample": (c_int, [P, c_int, c_int, c_int, P, P]),
         "ptops_gather_forward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_gather_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
@@ -107,6 +110,7 @@ EXPORTS = (
     "ptops_abi_version", "ptops_last_error", "ptops_chamfer_forward_workspace_bytes",
     "ptops_chamfer_forward", "ptops_chamfer_forward_ex", "ptops_chamfer_sweep_available",
     "ptops_chamfer_backward", "ptops_chamfer_backward_det_workspace_bytes", "ptops_chamfer_backward_det",
+    "ptops_chamfer_reduce_workspace_bytes", "ptops_chamfer_reduce", "ptops_chamfer_reduce_backward",
     "ptops_furthest_point_sample",
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
@@ -308,6 +312,43 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
             _chamfer_policy.record(st, stats, algos)
         chamfer_algorithm_log[(B, n, m)] = tuple(int(a) for a in algos)
     return dist1, dist2, idx1, idx2
+
+
+_chamfer_reduce_ws = {}      # (device index, stream) -> zero-armed workspace of ptops_chamfer_reduce
+
+
+def chamfer_reduce(dist1, dist2, take_sqrt):
+    """-> [4] = mean(f(dist1)), mean(f(dist2)), their sum, half their sum (f = sqrt or identity) in one launch
+    (csrc/chamfer.hip: the reductions of extensions/chamfer_dist/__init__.py:28-103; deterministic)."""
+    dev = _same_device(dist1, dist2)
+    for name, t in (("dist1", dist1), ("dist2", dist2)):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(f"chamfer_reduce: {name} must be a contiguous float32 tensor")
+    n1, n2 = dist1.numel(), dist2.numel()
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        need = int(load().ptops_chamfer_reduce_workspace_bytes(n1, n2))
+        key = (dev.index, stream.cuda_stream)
+        ws = _chamfer_reduce_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.zeros((max(need, 4096),), dtype=torch.uint8, device=dev)     # the counter starts (and stays) at zero
+            _chamfer_reduce_ws[key] = ws
+        out = torch.empty((4,), dtype=torch.float32, device=dev)
+        _call("ptops_chamfer_reduce", _ptr(dist1), n1, _ptr(dist2), n2, int(bool(take_sqrt)), _ptr(out), _ptr(ws),
+              ctypes.c_void_p(stream.cuda_stream))
+    return out
+
+
+def chamfer_reduce_backward(dist1, dist2, take_sqrt, which, go1, go2=None):
+    """Gradients of dist1 / dist2 for the gradient of one output of `chamfer_reduce`: `which` 2 / 3 -> of out[2] / out[3]
+    (go1, a one-element tensor), 0 -> of out[0] and out[1] (go1, go2; None = no gradient)."""
+    dev = _same_device(dist1, dist2)
+    with torch.cuda.device(dev):
+        g1, g2 = torch.empty_like(dist1), torch.empty_like(dist2)
+        _call("ptops_chamfer_reduce_backward", _ptr(dist1), dist1.numel(), _ptr(dist2), dist2.numel(), int(bool(take_sqrt)),
+              int(which), _ptr(go1) if go1 is not None else None, _ptr(go2) if go2 is not None else None, _ptr(g1), _ptr(g2),
+              _stream(dist1))
+    return g1, g2
 
 
 # True: scatter-add backward passes with a fixed summation order (bit-identical gradients from run to run) where the
@@ -675,15 +716,16 @@ def fold_mark_plain(*keys):
     _fold_plain.update(k for k in keys if k is not None)
 
 
-def fold_returning(key):
-    """Call where a backward node hands a possibly queued gradient of parameter `key` (any hashable, e.g. its
-    data_ptr) to autograd.  The first gradient of a parameter is adopted unread; a SECOND one in the same backward
-    pass (a module applied twice, or a plain aten path on the same parameter) is added to the first by the engine at
-    once, so everything queued is folded first."""
+def fold_returning(*keys):
+    """Call where a backward node hands a possibly queued gradient of the parameter(s) `keys` (any hashables, e.g. the
+    data_ptr of a leaf) to autograd.  The first gradient of a parameter is adopted unread; a SECOND one in the same
+    backward pass (a module applied twice, or a plain aten path on the same parameter) is added to the first by the
+    engine at once, so everything queued is folded first.  Keys must identify PARAMETERS: the address of a temporary
+    can be recycled within the pass."""
     if _fold_deferred:
-        if key in _fold_seen or key in _fold_plain:
+        if any(k in _fold_seen or k in _fold_plain for k in keys):
             fold_flush()
-        _fold_seen.add(key)
+        _fold_seen.update(keys)
 
 
 def fold_flush():

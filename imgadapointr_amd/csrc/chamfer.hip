@@ -785,3 +785,129 @@ PTOPS_API int ptops_chamfer_backward_det(const float* xyz1, const float* xyz2, c
   return ptops::check_launch("chamfer_grad_det_kernel");
 }
 
+
+// ---- reductions of the two distance vectors: ChamferDistanceL2 / L2_split / L1 / L1_PM ------------------------------
+// (extensions/chamfer_dist/__init__.py:28-103 of the reference: torch.mean / torch.sqrt / + / 2 on dist1 and dist2, six
+// element-wise / reduction launches forward and seven backward per loss term.)  One launch each way here:
+//   forward : out[0] = mean(f(dist1)), out[1] = mean(f(dist2)), out[2] = out[0] + out[1], out[3] = out[2] / 2,
+//             f = sqrt (take_sqrt) or identity; per-block partial sums, the last block to finish adds them in a fixed
+//             order (deterministic) and re-arms the counter;
+//   backward: the gradients of dist1 / dist2 for a gradient of one of those outputs, with autograd's own formulas
+//             (mean: g x (1 / N), sqrt: g / (2 * result), "/ 2": g / 2) in the same order, so the values are aten's.
+namespace {
+
+constexpr int kRedThreads = 256, kRedChunk = 4096;
+
+__device__ __forceinline__ float red_block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();                                       // sh may still be read from the previous use
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(kRedThreads) void chamfer_reduce_kernel(const float* __restrict__ d1, long long n1,
+                                                                     const float* __restrict__ d2, long long n2,
+                                                                     int take_sqrt, float* partial,
+                                                                     unsigned int* counter, float* __restrict__ out) {
+  __shared__ float sh[4];
+  __shared__ int is_last;
+  const int t = threadIdx.x;
+  const long long nb1 = ptops::ceil_div_ll(n1, kRedChunk), nb2 = ptops::ceil_div_ll(n2, kRedChunk);
+  const bool second = (long long)blockIdx.x >= nb1;
+  const float* d = second ? d2 : d1;
+  const long long n = second ? n2 : n1;
+  const long long base = ((long long)blockIdx.x - (second ? nb1 : 0)) * kRedChunk;
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < kRedChunk / kRedThreads; ++i) {
+    const long long j = base + (long long)i * kRedThreads + t;
+    if (j < n) {
+      const float v = d[j];
+      s += take_sqrt ? sqrtf(v) : v;
+    }
+  }
+  s = red_block_sum(s, sh);
+  if (t == 0) {
+    partial[blockIdx.x] = s;
+    __threadfence();
+    is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = t; i < nb1; i += kRedThreads) s1 += __builtin_nontemporal_load(partial + i);
+  for (long long i = t; i < nb2; i += kRedThreads) s2 += __builtin_nontemporal_load(partial + nb1 + i);
+  s1 = red_block_sum(s1, sh);
+  s2 = red_block_sum(s2, sh);
+  if (t == 0) {
+    // sum x (1 / N), the form of aten's mean kernel; 0 x inf = NaN for an empty cloud, as torch.mean
+    const float m1 = s1 * (1.0f / (float)n1), m2 = s2 * (1.0f / (float)n2);
+    out[0] = m1, out[1] = m2, out[2] = m1 + m2, out[3] = (m1 + m2) / 2.f;
+    *counter = 0u;
+  }
+}
+
+// which: 0 -> gradient of out[0] and out[1] separately (go1 / go2, either may be null = zero),
+//        2 -> of out[2] (go1), 3 -> of out[3] (go1)
+__global__ __launch_bounds__(256) void chamfer_reduce_grad_kernel(const float* __restrict__ d1, long long n1,
+                                                                  const float* __restrict__ d2, long long n2,
+                                                                  int take_sqrt, int which, const float* __restrict__ go1,
+                                                                  const float* __restrict__ go2, float* __restrict__ g1,
+                                                                  float* __restrict__ g2) {
+  float a = go1 ? *go1 : 0.f, b = which == 0 ? (go2 ? *go2 : 0.f) : a;
+  if (which == 3) a = a / 2.f, b = a;
+  // mean backward: g / N, which aten evaluates as g x (1 / N) for a scalar divisor (so does "/ 2", exactly)
+  const float ga = a * (1.0f / (float)n1), gb = b * (1.0f / (float)n2);
+  const long long total = n1 + n2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const bool second = i >= n1;
+    const long long j = second ? i - n1 : i;
+    const float g = second ? gb : ga;
+    const bool live = second ? (which != 0 || go2) : (go1 != nullptr);
+    float r = g;
+    if (take_sqrt) r = live ? g / (2.f * sqrtf((second ? d2 : d1)[j])) : 0.f;   // sqrt backward: g / (2 * result)
+    (second ? g2 : g1)[j] = r;
+  }
+}
+
+}  // namespace
+
+PTOPS_API size_t ptops_chamfer_reduce_workspace_bytes(long long n1, long long n2) {
+  return sizeof(float) * (size_t)(ptops::ceil_div_ll(n1 > 0 ? n1 : 0, kRedChunk) + ptops::ceil_div_ll(n2 > 0 ? n2 : 0, kRedChunk)) + 64;
+}
+
+// workspace: ptops_chamfer_reduce_workspace_bytes(n1, n2) bytes whose first 4 bytes are ZERO before the first use and
+// are left zero by every launch (keep one workspace per stream); out: 4 floats.
+PTOPS_API int ptops_chamfer_reduce(const float* dist1, long long n1, const float* dist2, long long n2, int take_sqrt,
+                                   float* out, void* workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(n1 >= 0 && n2 >= 0, "chamfer_reduce: negative size");
+  PTOPS_REQUIRE(out && workspace && (dist1 || n1 == 0) && (dist2 || n2 == 0), "chamfer_reduce: null pointer");
+  const long long blocks = ptops::ceil_div_ll(n1, kRedChunk) + ptops::ceil_div_ll(n2, kRedChunk);
+  PTOPS_REQUIRE(blocks < (1LL << 31), "chamfer_reduce: too many elements");
+  unsigned int* counter = (unsigned int*)workspace;
+  float* partial = (float*)((char*)workspace + 64);
+  // an empty problem still launches one block: it finds no work, is the last one and writes the NaN means
+  hipLaunchKernelGGL(chamfer_reduce_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(kRedThreads), 0, stream, dist1, n1,
+                     dist2, n2, take_sqrt, partial, counter, out);
+  return ptops::check_launch("chamfer_reduce_kernel");
+}
+
+PTOPS_API int ptops_chamfer_reduce_backward(const float* dist1, long long n1, const float* dist2, long long n2, int take_sqrt,
+                                            int which, const float* grad_out1, const float* grad_out2, float* grad_dist1,
+                                            float* grad_dist2, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(n1 >= 0 && n2 >= 0, "chamfer_reduce_backward: negative size");
+  PTOPS_REQUIRE(which == 0 || which == 2 || which == 3, "chamfer_reduce_backward: which must be 0, 2 or 3");
+  if (n1 + n2 == 0) return PTOPS_OK;
+  PTOPS_REQUIRE((grad_dist1 || n1 == 0) && (grad_dist2 || n2 == 0) && (which == 0 || grad_out1),
+                "chamfer_reduce_backward: null pointer");
+  PTOPS_REQUIRE(!take_sqrt || ((dist1 || n1 == 0) && (dist2 || n2 == 0)), "chamfer_reduce_backward: null distances");
+  const long long blocks = ptops::ceil_div_ll(n1 + n2, 256 * 8);
+  hipLaunchKernelGGL(chamfer_reduce_grad_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, dist1,
+                     n1, dist2, n2, take_sqrt, which, grad_out1, grad_out2, grad_dist1, grad_dist2);
+  return ptops::check_launch("chamfer_reduce_grad_kernel");
+}

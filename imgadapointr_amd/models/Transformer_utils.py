@@ -122,13 +122,35 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        ctx.bias_key = bias.data_ptr() if bias is not None else None
+        _note_parameter_keys(ctx, weight, bias)
         return linear_forward(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
         return _linear_backward(ctx, x, weight, grad, _take_column_sums(grad) if ctx.needs_input_grad[2] else None)
+
+
+def _note_parameter_keys(ctx, weight, bias):
+    """Identity of the PARAMETERS behind a layer's weight / bias for `_native.fold_returning` (a queued gradient must be
+    the first and only one its parameter gets before the flush).  A leaf (or a reshaped view of a whole leaf) is its own
+    address.  A derived tensor (the concatenated k/v weights of CrossAttention) names its leaves in `_ptops_keys`; one
+    that does not is unknown: its address may be recycled within the pass, so its gradients are never queued."""
+    def keys(t, tag):
+        if t is None:
+            return ()
+        named = getattr(t, "_ptops_keys", None)
+        if named is not None:
+            return tuple((tag, k) if tag else k for k in named)
+        if not t.is_leaf and t._is_view() and t._base is not None and t._base.is_leaf and t.numel() == t._base.numel() \
+                and t.is_contiguous() and t._base.is_contiguous():
+            t = t._base          # a reshaped view of a whole leaf (a 1x1 convolution's weight as a matrix): its gradient
+                                 # travels back as a view, unread
+        if t.is_leaf:
+            return ((tag, t.data_ptr()) if tag else t.data_ptr(),)
+        return None
+    ctx.weight_keys = keys(weight, "weight")
+    ctx.bias_keys = keys(bias, None)
 
 
 def _linear_backward(ctx, x, weight, grad, gb):
@@ -143,12 +165,13 @@ def _linear_backward(ctx, x, weight, grad, gb):
             gx = (g2 @ weight).view(x.shape)
     if ctx.needs_input_grad[1]:
         x2 = x.reshape(-1, x.size(-1))
-        if USE_SPLIT3_WGRAD and _native.wgrad_deferrable(g2, x2):
+        if USE_SPLIT3_WGRAD and ctx.weight_keys is not None and _native.wgrad_deferrable(g2, x2):
             # nothing reads a weight gradient before the end of backward: queue it for the grouped launch
             # (_native.wgrad_defer: all layers in two launches, tiles of a layer on one XCD, bias gradient included)
-            gw, db = _native.wgrad_defer(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
+            want_db = (ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0 and ctx.bias_keys is not None)
+            gw, db = _native.wgrad_defer(g2, x2, want_db)
             gb = db if db is not None else gb
-            _native.fold_returning(("weight", weight.data_ptr()))
+            _native.fold_returning(*ctx.weight_keys)
         elif _use_split3_wgrad(g2, x2):
             # the bias gradient (column sums of g2) falls out of the same pass
             gw, db = _native.gemm_split3_wgrad(g2, x2, ctx.needs_input_grad[2] and gb is None and g2.size(1) % 4 == 0)
@@ -160,7 +183,10 @@ def _linear_backward(ctx, x, weight, grad, gb):
     if not ctx.needs_input_grad[2]:
         gb = None
     if gb is not None:
-        _native.fold_returning(ctx.bias_key)       # gb may be a queued fold (include/ptops.h, deferred folds)
+        if ctx.bias_keys is None:
+            _native.fold_flush()                   # a bias of unknown provenance: nothing queued may reach it
+        else:
+            _native.fold_returning(*ctx.bias_keys)  # gb may be a queued fold (include/ptops.h, deferred folds)
     return gx, gw, gb
 
 
@@ -176,7 +202,7 @@ class _LinearGeluFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         u, g = _native.gemm_split3_gelu(x.view(-1, x.size(-1)), weight, bias)
         ctx.save_for_backward(x, weight, u)
-        ctx.bias_key = bias.data_ptr() if bias is not None else None
+        _note_parameter_keys(ctx, weight, bias)
         return g.view(*x.shape[:-1], weight.size(0))
 
     @staticmethod
@@ -677,6 +703,8 @@ class CrossAttention(nn.Module):
                 and (self.attn_drop.p == 0.0 or not self.training) and N % 32 == 0 and NK % 32 == 0):
             wkv = torch.cat([self.k_map.weight, self.v_map.weight], dim=0)            # [2C, C]: 1.2 MB, once per call
             bkv = torch.cat([self.k_map.bias, self.v_map.bias], dim=0)
+            wkv._ptops_keys = (self.k_map.weight.data_ptr(), self.v_map.weight.data_ptr())
+            bkv._ptops_keys = (self.k_map.bias.data_ptr(), self.v_map.bias.data_ptr())
             # the weight / bias gradients travel on through cat's backward as two dim-0 views each, which AccumulateGrad
             # adopts without reading (dense, strides of the parameter, sole owner): they may stay queued (deferred
             # folds / grouped weight gradients; test_cross_attention_fused_kv_projection runs this with poisoned outputs)

@@ -434,6 +434,29 @@ class _FusedEdgeConv(torch.autograd.Function):
         return dP, dR, None, dgb[:, 1], dgb[:, 0], None, None, None
 
 
+class _SplitEdgeWeight(torch.autograd.Function):
+    """w [C', 2C] = [W1 | W2] of an edge-conv stage -> (W1, W2 - W1): conv(cat(x_k[idx] - x_q, x_q)) = W1 x_k[idx] +
+    (W2 - W1) x_q.  One subtraction forward; backward gw = [g1 - g2 | g2] as one subtraction + one concat (autograd's
+    slicing would zero-fill and copy a full-size gradient per half and add them)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        C = w.size(1) // 2
+        return w[:, :C], w[:, C:] - w[:, :C]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat([g1 - g2, g2], dim=1)
+
+
+def _channel_first_linear(w, x):
+    """w [C', C], x [B, C, N] -> [B, C', N] = w . x[b] as ONE strided-batched GEMM with the weight broadcast over the
+    batch (batch stride 0): the output is contiguous channel-first as the edge kernels want it, and neither operand
+    is copied.  (torch.matmul(w, x) folds the batch into the rows instead, which costs a transposed copy of x going
+    in, one of the result coming out, and the same again in the backward pass.)"""
+    return torch.bmm(w.unsqueeze(0).expand(x.size(0), -1, -1), x)
+
+
 class DGCNN_Grouper(nn.Module):
     """Four edge-conv stages with two FPS down-samplings (base_blocks.py:516-629)."""
 
@@ -480,10 +503,9 @@ class DGCNN_Grouper(nn.Module):
         with torch.no_grad():
             idx = knn_idx(self.k, coor_k.transpose(-1, -2).contiguous(), coor_q.transpose(-1, -2).contiguous())
         C = x_k.size(1)
-        w = conv.weight.view(conv.out_channels, 2 * C)
-        w1, w2 = w[:, :C], w[:, C:]
-        P = torch.matmul(w1, x_k)                      # [B,C',Nk]   W1 . x_k
-        R = torch.matmul(w2 - w1, x_q)                 # [B,C',Nq]   (W2 - W1) . x_q
+        w1, w21 = _SplitEdgeWeight.apply(conv.weight.view(conv.out_channels, 2 * C))
+        P = _channel_first_linear(w1, x_k)             # [B,C',Nk]   W1 . x_k
+        R = _channel_first_linear(w21, x_q)            # [B,C',Nq]   (W2 - W1) . x_q
         return _FusedEdgeConv.apply(P, R, idx, norm.weight, norm.bias, norm.num_groups, norm.eps,
                                     act.negative_slope)
 
@@ -496,7 +518,7 @@ class DGCNN_Grouper(nn.Module):
         # GEMMs are reproducible.  Same parameters, same values.
         it = self.input_trans
         if isinstance(it, nn.Conv1d) and it.kernel_size == (1,) and it.groups == 1 and it.stride == (1,):
-            f = torch.matmul(it.weight.squeeze(-1), x)
+            f = _channel_first_linear(it.weight.squeeze(-1), x)
             if it.bias is not None:
                 f = f + it.bias.view(1, -1, 1)
         else:

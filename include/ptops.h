@@ -364,6 +364,22 @@ int ptops_gemm_f32_split3_wgrad(const float* dY, long long ldy, const float* X, 
                                 float* dW, long long lddw, float* db, void* workspace, long long workspace_bytes,
                                 void* stream);
 
+/* Reductions of the two Chamfer distance vectors - ChamferDistanceL2 / L2_split / L1 / L1_PM
+ * (extensions/chamfer_dist/__init__.py:28-103: torch.mean / torch.sqrt / + / 2) - one launch forward, one backward.
+ * forward: out[0] = mean(f(dist1)), out[1] = mean(f(dist2)), out[2] = out[0] + out[1], out[3] = out[2] / 2 with
+ * f = sqrt when take_sqrt else identity (n1, n2: element counts; mean of nothing is NaN as in torch).  Deterministic
+ * (block partials added in a fixed order by the last block).  workspace: *_workspace_bytes(n1, n2) bytes whose first 4
+ * bytes are zero before the first use; the kernel leaves them zero (one workspace per stream).
+ * backward: grad_dist1 / grad_dist2 for the gradient of out[which], which = 2 or 3 (grad_out1: one float on the
+ * device), or which = 0: of out[0] and out[1] separately (grad_out1 / grad_out2, NULL = zero), by autograd's own
+ * formulas (mean: g / N, sqrt: g / (2 result), "/ 2": g / 2) in autograd's order: aten's values. */
+size_t ptops_chamfer_reduce_workspace_bytes(long long n1, long long n2);
+int ptops_chamfer_reduce(const float* dist1, long long n1, const float* dist2, long long n2, int take_sqrt, float* out,
+                         void* workspace, void* stream);
+int ptops_chamfer_reduce_backward(const float* dist1, long long n1, const float* dist2, long long n2, int take_sqrt,
+                                  int which, const float* grad_out1, const float* grad_out2, float* grad_dist1,
+                                  float* grad_dist2, void* stream);
+
 /* The weight (and bias) gradients of MANY layers in two launches.  A layer's dW has few output tiles and a long
  * contraction, and nothing in a backward pass reads it before the optimizer: the host side queues the (dY, X) pairs
  * while autograd runs (torch's Linear backward, models/Transformer_utils.py:71-159 of the reference, computes each

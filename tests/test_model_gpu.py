@@ -78,6 +78,50 @@ def test_multi_view_batch_equals_separate_views():
     print(pc.check_multi_view("cuda", views=3))
 
 
+def test_fused_chamfer_reductions_equal_the_literal_chain():
+    """The one-node Chamfer + reduction (`ptops_chamfer_reduce`, one launch each way) against the literal torch.mean /
+    torch.sqrt chain of extensions/chamfer_dist/__init__.py:28-103 on the same HIP distances: values to the rounding of
+    a 2 x 20000-term float sum, gradients of both clouds bit for bit (autograd's formulas in autograd's order), for all
+    four reductions, a split reduction with one unused half, a scaled loss, and batch-1 `ignore_zeros`."""
+    from imgadapointr_amd.extensions import chamfer_dist as cd
+    torch.manual_seed(3)
+    a0 = torch.rand(5, 4000, 3, device="cuda") - 0.5
+    b0 = torch.rand(5, 3000, 3, device="cuda") - 0.5
+    a0[0, :40] = 0.0                                             # zero rows for ignore_zeros
+
+    def run(crit, fused, pick, a_in, b_in):
+        cd.FUSED_REDUCTIONS = fused
+        try:
+            a, b = a_in.clone().requires_grad_(True), b_in.clone().requires_grad_(True)
+            loss = pick(crit(a, b))
+            (loss * 0.37).backward()
+            return loss.detach(), a.grad, b.grad
+        finally:
+            cd.FUSED_REDUCTIONS = True
+
+    cases = [(cd.ChamferDistanceL1(), lambda r: r, a0, b0), (cd.ChamferDistanceL2(), lambda r: r, a0, b0),
+             (cd.ChamferDistanceL1_PM(), lambda r: r, a0, b0),
+             (cd.ChamferDistanceL2_split(), lambda r: r[0] + 3.0 * r[1], a0, b0),
+             (cd.ChamferDistanceL2_split(), lambda r: r[1], a0, b0),
+             (cd.ChamferDistanceL1(ignore_zeros=True), lambda r: r, a0[:1], b0[:1])]
+    for crit, pick, a_in, b_in in cases:
+        want, got = run(crit, False, pick, a_in, b_in), run(crit, True, pick, a_in, b_in)
+        name = type(crit).__name__
+        assert abs(want[0].item() - got[0].item()) <= 4e-7 * abs(want[0].item()), (name, want[0].item(), got[0].item())
+        for w, g in zip(want[1:], got[1:]):
+            if w is None:                                        # literal chain: no gradient at all for an unused cloud
+                assert g is None or float(g.abs().max()) == 0.0, name
+            else:
+                assert torch.equal(w, g), (name, float((w - g).abs().max()))
+    # determinism of the forward sum, and torch.mean's NaN for an empty cloud
+    x = cd.ChamferDistanceL1()(a0, b0)
+    assert all(torch.equal(x, cd.ChamferDistanceL1()(a0, b0)) for _ in range(3))
+    from imgadapointr_amd import _native
+    e = torch.empty(0, device="cuda")
+    out = _native.chamfer_reduce(e, torch.ones(7, device="cuda"), True)
+    assert torch.isnan(out[0]) and out[1].item() == 1.0 and torch.isnan(out[2])
+
+
 def test_chamfer_reductions_on_the_hip_path():
     """ChamferDistanceL1 / L2 / L2_split / L1_PM and `ignore_zeros` (extensions/chamfer_dist/__init__.py:28-103 of the
     reference) through libptops against the reference fixture (reference Python over the oracle's distances), plus the
