@@ -54,6 +54,7 @@ def main():
         rows = {e.key: (e.count / 3, e.self_device_time_total / 3e3) for e in prof.key_averages()}
         for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:14]:
             print(f"     {t:8.3f} ms  x{c:6.1f}  {k[:100]}")
+        print(f"     problem-table uploads so far: {_native.wgrad_table_uploads[0]}")
         print(f"     total kernel time {sum(t for _, t in rows.values()):.3f} ms, {sum(c for c, _ in rows.values()):.0f} launches")
     TU.FUSED_KV_PROJECTION = True
 

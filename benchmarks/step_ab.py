@@ -14,6 +14,8 @@ import bench  # noqa: E402
 from imgadapointr_amd import _native  # noqa: E402
 from imgadapointr_amd.models import Transformer_utils as TU  # noqa: E402
 from imgadapointr_amd.models import build_model_from_cfg  # noqa: E402
+from imgadapointr_amd.extensions import chamfer_dist  # noqa: E402
+from imgadapointr_amd.pointnet2_ops import pointnet2_utils  # noqa: E402
 from imgadapointr_amd.tools import builder, runner  # noqa: E402
 from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
 
@@ -45,6 +47,8 @@ def main():
             ("immediate folds (and weight gradients)", attr(runner, "DEFER_FOLDS", False)),
             ("weight gradients per layer, not grouped", attr(_native, "GROUPED_WGRAD", False)),
             ("k_map and v_map as two projections", attr(TU, "FUSED_KV_PROJECTION", False)),
+            ("farthest point sampling on a side stream", attr(pointnet2_utils, "OVERLAP_FPS", True)),
+            ("Chamfer reductions as the literal torch chain", attr(chamfer_dist, "FUSED_REDUCTIONS", False)),
             ("Chamfer MFMA with fragment prefetch", opt("PTOPS_CHAMFER_MFMA_PREFETCH", 1))]
     for _ in range(8):
         step(partial, gt)

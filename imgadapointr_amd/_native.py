@@ -879,6 +879,8 @@ GROUPED_WGRAD = os.environ.get("PTOPS_GROUPED_WGRAD", "1") != "0"
 _wgrad_queue = []             # (dy, x, dW pointer, db pointer or 0, M, N, K): operands alive until the flush
 _wgrad_plans = {}             # (device index, shapes) -> (host plan bytes, device plan, workspace bytes)
 _wgrad_ws = {}                # device index -> workspace tensor
+_wgrad_tables = {}            # plan key -> {bytes of a host table: the same table on the device} (the last few)
+wgrad_table_uploads = [0]     # how often the device table had to be rewritten (diagnostics)
 
 
 def wgrad_deferrable(dy, x):
@@ -944,11 +946,27 @@ def wgrad_flush():
         assert lib.ptops_wgrad_problem_bytes() == 72
         for i, (dy, x, pw, pb, M, N, K, _sw, _sb) in enumerate(queue):
             rows[i] = (dy.data_ptr(), x.data_ptr(), pw, pb, dy.stride(0), x.stride(0), K, M | (N << 32), K)
-        pinned = torch.from_numpy(rows).pin_memory()
-        rows_dev = pinned.to(dev, non_blocking=True)
+        # The caching allocator hands a fixed-shape training loop the same blocks step after step, so the table of
+        # pointers usually IS last step's table, still on the device: upload only when it differs (a host-to-device copy
+        # in the middle of the stream costs ~0.2 ms of idle GPU on this stack: profiles/round3/idle_gaps_v1.log)
+        # (the allocator may alternate between a few block assignments: keep the last few tables per plan)
+        tables = _wgrad_tables.setdefault(key, {})
+        if len(_wgrad_tables) > 16:
+            _wgrad_tables.clear()
+            tables = _wgrad_tables.setdefault(key, {})
+        sig = rows.tobytes()
+        rows_dev = tables.get(sig)
+        if rows_dev is None:
+            if len(tables) >= 8:                                # recycle the oldest device table (stream order: after
+                rows_dev = tables.pop(next(iter(tables)))       # its last readers)
+            else:
+                rows_dev = torch.empty((n, 9), dtype=torch.int64, device=dev)
+            rows_dev.copy_(torch.from_numpy(rows).pin_memory(), non_blocking=True)
+            tables[sig] = rows_dev
+            wgrad_table_uploads[0] += 1
         _call("ptops_gemm_f32_split3_wgrad_grouped", ctypes.c_void_p(rows.ctypes.data), _ptr(rows_dev), n,
               ctypes.c_void_p(host_plan.ctypes.data), _ptr(dev_plan), _ptr(ws), ws.numel(), handle)
-        # `queue` (operands, output storages) and rows_dev die here: the launches are queued behind them in stream order
+        # `queue` (operands, output storages) dies here: the launches are queued behind it in stream order
 
 
 def adamw_clip_step(rows_dev, n_tensors, chunks_dev, n_chunks, max_norm, beta1, beta2, eps, partial, norm_coef):
@@ -1089,17 +1107,17 @@ def batch_norm_rows_backward(dy, x, stats, weight, bias, slope):
     return dx, dbg
 
 
-def edge_select(P, R, idx, take_max):
-    """P [B,C,Nk], R [B,C,Nq], idx int32 [B,Nq,k], take_max uint8 [C] ->
+def edge_select(P, R, idx, gamma):
+    """P [B,C,Nk], R [B,C,Nq], idx int32 [B,Nq,k], gamma float32 [C] (max over the neighbours where gamma >= 0, else min) ->
     (ysel [B,C,Nq], nsel int32 [B,C,Nq], ysum [B,C,Nq], partial [B,C,nblk,2])."""
     _check(P, "P", torch.float32, 3)
     _check(R, "R", torch.float32, 3)
     _check(idx, "idx", torch.int32, 3)
-    _check(take_max, "take_max", torch.uint8, 1)
-    dev = _same_device(P, R, idx, take_max)
+    _check(gamma, "gamma", torch.float32, 1)
+    dev = _same_device(P, R, idx, gamma)
     B, C, Nk = P.shape
     Nq, k = idx.shape[1], idx.shape[2]
-    if tuple(R.shape) != (B, C, Nq) or idx.shape[0] != B or take_max.numel() != C:
+    if tuple(R.shape) != (B, C, Nq) or idx.shape[0] != B or gamma.numel() != C:
         raise ValueError("edge_select: inconsistent shapes")
     nblk = load().ptops_edge_select_blocks(Nq)
     with torch.cuda.device(dev):
@@ -1107,7 +1125,7 @@ def edge_select(P, R, idx, take_max):
         nsel = torch.empty((B, C, Nq), dtype=torch.int32, device=dev)
         ysum = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
         partial = torch.empty((B, C, nblk, 2), dtype=torch.float32, device=dev)
-        _call("ptops_edge_select", _ptr(P), _ptr(R), _ptr(idx), _ptr(take_max), B, C, Nk, Nq, k, _ptr(ysel),
+        _call("ptops_edge_select", _ptr(P), _ptr(R), _ptr(idx), _ptr(gamma), B, C, Nk, Nq, k, _ptr(ysel),
               _ptr(nsel), _ptr(ysum), _ptr(partial), _stream(P))
     return ysel, nsel, ysum, partial
 

@@ -27,7 +27,7 @@ constexpr int kMaxK = 32;
 
 __global__ __launch_bounds__(kTPB) void edge_select_kernel(
     const float* __restrict__ P, const float* __restrict__ R, const int32_t* __restrict__ idx,
-    const unsigned char* __restrict__ take_max, int C, int Nk, int Nq, int k, float* __restrict__ ysel,
+    const float* __restrict__ gamma, int C, int Nk, int Nq, int k, float* __restrict__ ysel,
     int32_t* __restrict__ nsel, float* __restrict__ ysum, float* __restrict__ partial) {
   __shared__ float red[2][kTPB / 64];
   const int b = blockIdx.z, c0 = blockIdx.y * kCT;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kTPB) void edge_select_kernel(
     if (c >= C) break;  // uniform
     const float* prow = P + ((size_t)b * C + c) * Nk;
     const float r = in ? R[((size_t)b * C + c) * Nq + q] : 0.0f;
-    const bool mx = take_max[c] != 0;
+    const bool mx = gamma[c] >= 0.0f;       // the affine + LeakyReLU that follow are increasing in y iff gamma >= 0
     float best = 0.0f, s1 = 0.0f, s2 = 0.0f;
     int bn = 0;
 #pragma unroll
@@ -442,16 +442,16 @@ size_t csr_workspace_bytes(int B, int Nk, int Nq, int k) {
 
 PTOPS_API int ptops_edge_select_blocks(int Nq) { return ptops::ceil_div(Nq, kTPB); }
 
-PTOPS_API int ptops_edge_select(const float* P, const float* R, const int32_t* idx, const unsigned char* take_max,
+PTOPS_API int ptops_edge_select(const float* P, const float* R, const int32_t* idx, const float* gamma,
                                 int B, int C, int Nk, int Nq, int k, float* ysel, int32_t* nsel, float* ysum,
                                 float* partial, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTOPS_REQUIRE(B >= 0 && C >= 1 && Nk >= 1 && Nq >= 1 && k >= 1 && k <= kMaxK, "edge_select: bad size (k <= %d)", kMaxK);
   if (B == 0) return PTOPS_OK;
-  PTOPS_REQUIRE(P && R && idx && take_max && ysel && nsel && ysum && partial, "edge_select: null pointer");
+  PTOPS_REQUIRE(P && R && idx && gamma && ysel && nsel && ysum && partial, "edge_select: null pointer");
   PTOPS_REQUIRE(B <= 65535, "edge_select: B exceeds grid limit");
   dim3 grid(ptops::ceil_div(Nq, kTPB), ptops::ceil_div(C, kCT), B);
-  hipLaunchKernelGGL(edge_select_kernel, grid, dim3(kTPB), 0, stream, P, R, idx, take_max, C, Nk, Nq, k, ysel, nsel,
+  hipLaunchKernelGGL(edge_select_kernel, grid, dim3(kTPB), 0, stream, P, R, idx, gamma, C, Nk, Nq, k, ysel, nsel,
                      ysum, partial);
   return ptops::check_launch("edge_select_kernel");
 }

@@ -134,10 +134,12 @@ class PCTransformer(nn.Module):
             img = img.flatten(0, 1)
         n_seed = self.num_query // 2
         need = max(self.center_num[0], n_seed, self.denoise_num if self.training else 0)
-        fps_idx = pointnet2_utils.furthest_point_sample(xyz, need)        # one run, three uses
+        # one run, three uses; on a side stream underneath the first kNN + edge-conv stage, which does not need it
+        fps_handle = pointnet2_utils.furthest_point_sample_async(xyz, need)
         xyz_cf = xyz.transpose(1, 2).contiguous()
 
-        coor, f = self.grouper(xyz, self.center_num, fps_idx=fps_idx)      # [B,256,3], [B,256,128]
+        coor, f = self.grouper(xyz, self.center_num, fps_idx=fps_handle)   # [B,256,3], [B,256,128]
+        fps_idx = fps_handle.result()
         pe = self.pos_embed(coor)
         x = self.input_proj(f)
         x = self.encoder(x + pe, coor)

@@ -53,6 +53,33 @@ def _zero_i64(device):
 SPLIT_BROADCAST_LINEAR = True
 
 
+class _SplitColumns(torch.autograd.Function):
+    """w [O, I] -> (w[:, :c], w[:, c:]) as views; the backward is ONE concat of the two gradients.  (Autograd's own
+    slicing zero-fills and copies a full-size gradient per half and adds the two: five launches.)"""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        return w[:, :c], w[:, c:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat([g1, g2], dim=1), None
+
+
+class _SplitEdgeWeight(torch.autograd.Function):
+    """w [C', 2C] = [W1 | W2] of an edge layer -> (W1, W2 - W1): W . cat(x_k[idx] - x_q, x_q) = W1 x_k[idx] +
+    (W2 - W1) x_q.  One subtraction forward; backward gw = [g1 - g2 | g2] as one subtraction + one concat."""
+
+    @staticmethod
+    def forward(ctx, w):
+        C = w.size(1) // 2
+        return w[:, :C], w[:, C:] - w[:, :C]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat([g1 - g2, g2], dim=1)
+
+
 def linear_on_broadcast_concat(lin, g, x):
     """lin(cat([g.unsqueeze(1).expand(-1, M, -1), x], -1)) for g [B,G], x [B,M,X], lin: Linear(G+X, O)."""
     if not SPLIT_BROADCAST_LINEAR:
@@ -60,8 +87,9 @@ def linear_on_broadcast_concat(lin, g, x):
     G = g.size(-1)
     if torch.is_grad_enabled():                                 # plain autograd path: see _native.deferred_folds
         _native.fold_mark_plain(("weight", lin.weight.data_ptr()), lin.bias.data_ptr() if lin.bias is not None else None)
-    per_cloud = F.linear(g, lin.weight[:, :G], lin.bias)        # [B,O]
-    return F.linear(x, lin.weight[:, G:]) + per_cloud.unsqueeze(1)
+    w_g, w_x = _SplitColumns.apply(lin.weight, G)
+    per_cloud = F.linear(g, w_g, lin.bias)                      # [B,O]
+    return F.linear(x, w_x) + per_cloud.unsqueeze(1)
 
 
 # Dense layers on libptops' fp32-on-bf16-matrix-pipe GEMM (csrc/gemm_split3.hip: operands split into three bf16 pieces,
@@ -430,11 +458,14 @@ class _GatherMax(torch.autograd.Function):
         ctx.save_for_backward(arg)
         ctx.N = p.size(1)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)         # no zero tensor for the (integer) second output
         return out, arg
 
     @staticmethod
     def backward(ctx, grad_out, _grad_arg):
         (arg,) = ctx.saved_tensors
+        if grad_out is None:
+            return None, None
         return _native.gather_max_backward(grad_out.contiguous(), arg, ctx.N), None
 
 
@@ -733,9 +764,9 @@ class DynamicGraphAttention(nn.Module):
         C = self.dim
         lin = self.knn_map[0]
         if FUSED_GRAPH_ATTENTION:
-            w1, w2 = lin.weight[:, :C], lin.weight[:, C:]
+            w1, w21 = _SplitEdgeWeight.apply(lin.weight)
             p = F.linear(v, w1)                    # per source token
-            qt = F.linear(q, w2 - w1, lin.bias)    # per query token
+            qt = F.linear(q, w21, lin.bias)        # per query token
             return F.leaky_relu(gather_max(p, idx) + qt, 0.2)
         local_v = index_points(v, idx)             # [B,S,k,C]
         qe = q.unsqueeze(-2).expand(-1, -1, idx.size(-1), -1)

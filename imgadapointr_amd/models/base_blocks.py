@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import _native
 from ..pointnet2_ops import pointnet2_utils
 from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention, LayerNorm, LayerScale, Linear, Mlp,
-                                add_layer_norm,
+                                _SplitEdgeWeight, add_layer_norm,
                                 knn_idx, linear_on_broadcast_concat, max_over_tokens)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
@@ -416,8 +416,7 @@ class _FusedEdgeConv(torch.autograd.Function):
     def forward(ctx, P, R, idx, gamma, beta, groups, eps, slope):
         P, R = P.contiguous(), R.contiguous()
         k = idx.shape[2]
-        take_max = (gamma >= 0).to(torch.uint8)
-        ysel, nsel, ysum, partial = _native.edge_select(P, R, idx, take_max)
+        ysel, nsel, ysum, partial = _native.edge_select(P, R, idx, gamma.detach())
         out, mean_rstd = _native.edge_norm_forward(ysel, partial, gamma, beta, groups, k, eps, slope)
         ctx.save_for_backward(P, R, idx, gamma, beta, nsel, ysum, ysel, mean_rstd)
         ctx.slope = slope
@@ -430,23 +429,8 @@ class _FusedEdgeConv(torch.autograd.Function):
         # the selected edges only); the kernels turn that into dP, dR and the per-(b,c) sums behind dgamma / dbeta
         dP, dR, sums = _native.edge_norm_backward(go.contiguous(), ysel, ysum, P, R, idx, nsel, gamma, beta, mean_rstd,
                                                   ctx.slope)
-        dgb = sums.sum(dim=0)
-        return dP, dR, None, dgb[:, 1], dgb[:, 0], None, None, None
-
-
-class _SplitEdgeWeight(torch.autograd.Function):
-    """w [C', 2C] = [W1 | W2] of an edge-conv stage -> (W1, W2 - W1): conv(cat(x_k[idx] - x_q, x_q)) = W1 x_k[idx] +
-    (W2 - W1) x_q.  One subtraction forward; backward gw = [g1 - g2 | g2] as one subtraction + one concat (autograd's
-    slicing would zero-fill and copy a full-size gradient per half and add them)."""
-
-    @staticmethod
-    def forward(ctx, w):
-        C = w.size(1) // 2
-        return w[:, :C], w[:, C:] - w[:, :C]
-
-    @staticmethod
-    def backward(ctx, g1, g2):
-        return torch.cat([g1 - g2, g2], dim=1)
+        dgb = sums.permute(0, 2, 1).sum(dim=0)           # [2, C]: contiguous rows for AccumulateGrad (no clone per half)
+        return dP, dR, None, dgb[1], dgb[0], None, None, None
 
 
 def _channel_first_linear(w, x):
@@ -478,14 +462,16 @@ class DGCNN_Grouper(nn.Module):
     def fps_downsample(coor, x, num_group, fps_idx=None):
         """coor [B,3,N], x [B,C,N] -> the num_group farthest points and their features.
         `fps_idx` (int32 [B,>=num_group]) lets the caller share one sampling run."""
+        if isinstance(fps_idx, pointnet2_utils.FpsHandle):
+            fps_idx = fps_idx.result()
         if fps_idx is None:
             xyz = coor.transpose(1, 2).contiguous()
             fps_idx = pointnet2_utils.furthest_point_sample(xyz, num_group)
         else:
             fps_idx = fps_idx[:, :num_group].contiguous()
-        combined = torch.cat([coor, x], dim=1)
-        new_combined = pointnet2_utils.gather_operation(combined, fps_idx)
-        return new_combined[:, :3], new_combined[:, 3:]
+        # two gathers: the reference's cat + gather + two slices (base_blocks.py:556-562) costs a concat going in and, in
+        # the backward pass, a zero-fill + copy per slice and a split of the gathered gradient
+        return pointnet2_utils.gather_operation(coor, fps_idx), pointnet2_utils.gather_operation(x, fps_idx)
 
     def get_graph_feature(self, coor_q, x_q, coor_k, x_k):
         """coor [B,3,N*], x [B,C,N*] -> [B,2C,Nq,k] = cat(x_k[idx] - x_q, x_q)  (base_blocks.py:565-588)."""
@@ -527,12 +513,16 @@ class DGCNN_Grouper(nn.Module):
         f = self.edge_conv(self.layer1, coor, f, coor, f)
 
         coor_q, f_q = self.fps_downsample(coor, f, num[0], fps_idx=fps_idx)
+        # the second sampling needs the first one's coordinates only: start it now, on the side stream, under stages 2 and 3
+        fps2 = None
+        if coor_q.dtype == torch.float32:
+            fps2 = pointnet2_utils.furthest_point_sample_async(coor_q.detach().transpose(1, 2).contiguous(), num[1])
         f = self.edge_conv(self.layer2, coor_q, f_q, coor, f)
         coor = coor_q.contiguous()
 
         f = self.edge_conv(self.layer3, coor, f, coor, f)
 
-        coor_q, f_q = self.fps_downsample(coor, f, num[1])
+        coor_q, f_q = self.fps_downsample(coor, f, num[1], fps_idx=fps2)
         f = self.edge_conv(self.layer4, coor_q, f_q, coor, f)
         coor = coor_q
 

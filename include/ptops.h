@@ -271,14 +271,14 @@ int ptops_gelu_backward_colsum(const float* x, const float* dy, int M, int N, fl
 /* ------------------------------------------------- fused edge-conv stage ----
  * One stage of DGCNN_Grouper (models/base_blocks.py:565-623): with P = W1.x_k [B,C,Nk] and
  * R = (W2-W1).x_q [B,C,Nq] (the 1x1 convolution split over its two input halves) the value on edge
- * (q,j) is y = P[idx[q,j]] + R[q].  ptops_edge_select returns per (b,c,q) the max (take_max[c] != 0)
- * or min of y over the k neighbours (ysel), the source index that produced it (nsel), sum_j y (ysum) and
+ * (q,j) is y = P[idx[q,j]] + R[q].  ptops_edge_select returns per (b,c,q) the max (gamma[c] >= 0, gamma [C] = the
+ * GroupNorm scale: the affine + LeakyReLU after it are monotone in y) or min of y over the k neighbours (ysel), the source index that produced it (nsel), sum_j y (ysum) and
  * per-workgroup partial sums {sum y, sum y^2} (partial [B,C,ptops_edge_select_blocks(Nq),2]) for the
  * GroupNorm statistics.  ptops_edge_scatter is the edge part of the backward:
  * T[b,c,n] = sum_{(q,j): idx[q,j]=n} dense[b,c,q] + sum_{q: nsel[b,c,q]=n} sel[b,c,q].   k <= 32. */
 int ptops_edge_select_blocks(int Nq);
 int ptops_edge_select(const float* P, const float* R, const int32_t* idx,
-                      const unsigned char* take_max, int B, int C, int Nk, int Nq, int k,
+                      const float* gamma, int B, int C, int Nk, int Nq, int k,
                       float* ysel, int32_t* nsel, float* ysum, float* partial, void* stream);
 int ptops_edge_scatter(const float* dense, const float* sel, const int32_t* idx,
                        const int32_t* nsel, int B, int C, int Nk, int Nq, int k, float* T,

@@ -44,6 +44,72 @@ def test_workspace_query_is_pure_host_code():
     assert lib.ptops_chamfer_forward_workspace_bytes(0, 10, 10) == 0
 
 
+def test_wgrad_group_plan_is_a_partition_of_the_work():
+    """`ptops_wgrad_group_plan` (pure host code): every (problem, contraction split, tile) is exactly one job, the splits of
+    a problem cover its k-steps once, all tiles of a (problem, split) sit in ONE XCD queue (job index mod 8), the queues
+    are balanced, every output element has exactly one reduce job, and the workspace ranges do not overlap."""
+    import numpy as np
+    from imgadapointr_amd import _native
+    lib = _native.load()
+    mnk = np.array([[18432, 384, 384]] * 9 + [[18432, 1152, 384]] * 3 + [[8192, 384, 768]] * 4 + [[2048, 200, 132], [16, 128, 128],
+                   [4624, 96, 512]], dtype=np.int32)
+    want_db = np.array([i % 2 for i in range(len(mnk))], dtype=np.uint8)
+    n = len(mnk)
+    for target in (0, 24, 100, 100000):
+        need = lib.ptops_wgrad_group_plan(mnk.ctypes.data, want_db.ctypes.data, n, target, None, 0)
+        assert need > 0
+        blob = np.zeros(need, dtype=np.uint8)
+        assert lib.ptops_wgrad_group_plan(mnk.ctypes.data, want_db.ctypes.data, n, target, blob.ctypes.data, need) == need
+        head = blob[:16].view(np.int32)
+        n_jobs, n_rjobs = int(head[2]), int(head[3])
+        assert int(head[1]) == n and n_jobs % 8 == 0
+        ws_bytes = int(blob[16:24].view(np.int64)[0])
+        assert ws_bytes == lib.ptops_wgrad_group_workspace_bytes(blob.ctypes.data)
+        pp = blob[32:32 + 32 * n]
+        part_base = pp.view(np.int64).reshape(n, 4)[:, 0]
+        bpart_base = pp.view(np.int64).reshape(n, 4)[:, 1]
+        ints = pp.view(np.int32).reshape(n, 8)
+        splits, per, tiles_k = ints[:, 4], ints[:, 5], ints[:, 6]
+        jobs = blob[32 + 32 * n:32 + 32 * n + 16 * n_jobs].view(np.int32).reshape(n_jobs, 4)
+        rjobs = blob[32 + 32 * n + 16 * n_jobs:].view(np.int32).reshape(n_rjobs, 4)
+        seen, queue_of, load = set(), {}, np.zeros(8)
+        for j, (p, tile, split, _) in enumerate(jobs):
+            if p < 0:
+                continue
+            M, N, K = mnk[p]
+            tiles = -(-N // 128) * -(-K // 128)
+            assert 0 <= tile < tiles and 0 <= split < splits[p] and tiles_k[p] == -(-K // 128)
+            assert (p, tile, split) not in seen
+            seen.add((p, tile, split))
+            assert queue_of.setdefault((p, split), j % 8) == j % 8
+            load[j % 8] += min(per[p], M // 16 - split * per[p])
+        for p, (M, N, K) in enumerate(mnk):
+            tiles = -(-N // 128) * -(-K // 128)
+            assert all((p, t, s) in seen for t in range(tiles) for s in range(splits[p]))
+            assert (splits[p] - 1) * per[p] < M // 16 <= splits[p] * per[p]          # no empty split, full cover
+        assert len(seen) == sum(-(-N // 128) * -(-K // 128) * splits[p] for p, (M, N, K) in enumerate(mnk))
+        assert load.max() - load.min() <= max(per.max() * 27, 0.2 * load.mean())     # within one (largest) group
+        # reduce jobs: 1024-float chunks of every dW, and of db where asked
+        for p, (M, N, K) in enumerate(mnk):
+            chunks = sorted(c for q, kind, c, _ in rjobs if q == p and kind == 0)
+            assert chunks == list(range(-(-N * K // 1024)))
+            chunks = sorted(c for q, kind, c, _ in rjobs if q == p and kind == 1)
+            assert chunks == (list(range(-(-N // 1024))) if want_db[p] else [])
+        # workspace ranges (floats) in order, inside the workspace
+        end = 0
+        for p, (M, N, K) in enumerate(mnk):
+            assert part_base[p] >= end and part_base[p] % 4 == 0
+            end = part_base[p] + splits[p] * N * K
+            if want_db[p]:
+                assert bpart_base[p] >= end and bpart_base[p] % 4 == 0
+                end = bpart_base[p] + splits[p] * N
+        assert end * 4 <= ws_bytes
+    assert lib.ptops_wgrad_group_plan(np.array([[100, 8, 8]], dtype=np.int32).ctypes.data, None, 1, 0, None, 0) == -1
+    assert lib.ptops_wgrad_group_plan(np.array([[128, 6, 8]], dtype=np.int32).ctypes.data,
+                                      np.array([1], dtype=np.uint8).ctypes.data, 1, 0, None, 0) == -1        # db needs N % 4
+    assert lib.ptops_wgrad_problem_bytes() == 72
+
+
 def test_no_cpu_fallback():
     import pytest
     import torch

@@ -583,6 +583,73 @@ def test_gemm_split3_wgrad_and_bias_gradient(native, M, N, K):
             native.gemm_split3_wgrad(dy[:M - 8], x[:M - 8])             # M % 16 != 0
 
 
+def test_grouped_weight_gradients(native):
+    """`ptops_gemm_f32_split3_wgrad_grouped`: the dW / db of a ragged mix of layers (tiles that do not fill 128 x 128,
+    contractions that do not divide into equal jobs, row-sliced operands, with and without db, a one-job problem) from ONE
+    grouped launch against float64 - not worse than the library GEMM / torch.sum - bit-identical across runs, for
+    several job lengths, and equal to the per-layer kernel's accuracy class; the C side refuses a plan that does not
+    belong to the problems."""
+    import ctypes
+    import numpy as np
+    torch.manual_seed(77)
+    shapes = [(18432, 384, 384, True), (8192, 1152, 384, False), (2048, 200, 132, True), (16, 128, 128, True),
+              (4096, 4, 4, True), (4624, 96, 512, True), (8192, 384, 768, False), (18432, 384, 384, True)]
+    probs = []
+    for M, N, K, wb in shapes:
+        x = (torch.randn(M, K + 8, device="cuda") * torch.logspace(-2, 2, K + 8, device="cuda"))[:, 4:4 + K]
+        dy = (torch.randn(M, N + 4, device="cuda") + 0.25)[:, :N]
+        probs.append((dy, x, wb))
+
+    def rel(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    def run():
+        outs = [native.wgrad_defer(dy, x, wb) for dy, x, wb in probs]
+        native.wgrad_flush()
+        return outs
+
+    first = None
+    for target in (0, 24, 100, 4096):
+        native.set_option("PTOPS_WGRAD_GROUP_STEPS", target)
+        native._wgrad_plans.clear()
+        try:
+            outs = run()
+            again = run()
+        finally:
+            native.set_option("PTOPS_WGRAD_GROUP_STEPS", 0)
+            native._wgrad_plans.clear()
+        for (dy, x, wb), (dw, db), (dw2, db2) in zip(probs, outs, again):
+            ref_w = dy.double().t() @ x.double()
+            assert rel(dw, ref_w) <= max(4.0 * rel(dy.t() @ x, ref_w), 1e-5), (target, tuple(dy.shape), rel(dw, ref_w))
+            assert torch.equal(dw, dw2)
+            assert (db is not None) == wb
+            if wb:
+                ref_b = dy.double().sum(0)
+                assert rel(db, ref_b) <= max(4.0 * rel(dy.sum(0), ref_b), 1e-5), (target, tuple(dy.shape), rel(db, ref_b))
+                assert torch.equal(db, db2)
+        first = first or outs
+    # the same layer twice in one group: two independent, equal results
+    assert torch.equal(first[0][0], first[7][0]) is False                  # different random operands ...
+    dup = [probs[0], probs[0]]
+    outs = [native.wgrad_defer(dy, x, wb) for dy, x, wb in dup]
+    native.wgrad_flush()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # plan / problem mismatch is refused on the host, before anything is launched
+    lib = native.load()
+    mnk = np.array([[4096, 128, 128]], dtype=np.int32)
+    need = lib.ptops_wgrad_group_plan(mnk.ctypes.data, None, 1, 0, None, 0)
+    plan = np.zeros(need, dtype=np.uint8)
+    assert lib.ptops_wgrad_group_plan(mnk.ctypes.data, None, 1, 0, plan.ctypes.data, need) == need
+    dy, x = torch.randn(2048, 128, device="cuda"), torch.randn(2048, 128, device="cuda")
+    dw = torch.empty(128, 128, device="cuda")
+    row = np.array([[dy.data_ptr(), x.data_ptr(), dw.data_ptr(), 0, 128, 128, 128, 2048 | (128 << 32), 128]], dtype=np.int64)
+    ws = torch.empty(int(lib.ptops_wgrad_group_workspace_bytes(plan.ctypes.data)), dtype=torch.uint8, device="cuda")
+    rc = lib.ptops_gemm_f32_split3_wgrad_grouped(row.ctypes.data, torch.from_numpy(row).cuda().data_ptr(), 1, plan.ctypes.data,
+                                                 torch.from_numpy(plan).cuda().data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc != 0 and b"plan" in lib.ptops_last_error()
+    assert lib.ptops_wgrad_group_plan(np.array([[100, 8, 8]], dtype=np.int32).ctypes.data, None, 1, 0, None, 0) == -1   # M % 16
+
+
 def test_linear_layers_on_split3_match_library(native):
     """nn.Linear-compatible module: forward, input gradient, weight gradient and bias gradient with the split-bf16 GEMM
     switched on and off agree to fp32 accuracy (each is compared with float64)."""
