@@ -210,7 +210,8 @@ class AttentionProbe:
 
 class GemmProbe:
     """Events around every dense-layer GEMM that runs on libptops' split-bf16 kernels during one timed step (forward,
-    input gradient, weight gradient incl. its reduction, Linear + GELU): fp32 product FLOPs per second (`achieved`) and
+    input gradient, weight gradients - per layer or the grouped launch of all queued layers incl. its reduction -,
+    Linear + GELU): fp32 product FLOPs per second (`achieved`) and
     the executed bf16 piece-product FLOPs (x 6) against the dense bf16 peak (`frac`).  The remaining GEMMs of the step are
     hipBLASLt / rocBLAS fp32-MFMA kernels (profiles/round2/step_breakdown_v4.txt)."""
     NAMES = ("gemm_split3", "gemm_split3_wgrad", "gemm_split3_gelu")
@@ -221,6 +222,21 @@ class GemmProbe:
         self.rec = []
         for n in self.NAMES:
             setattr(_native, n, self._wrap(n))
+        # the grouped weight-gradient launch (all queued layers in one kernel + one reduction): its FLOPs are the queue's
+        self.orig_flush = _native.wgrad_flush
+
+        def flush():
+            if not (self.enabled and _native._wgrad_queue):
+                return self.orig_flush()
+            flops = sum(2.0 * q[4] * q[5] * q[6] for q in _native._wgrad_queue)
+            n = len(_native._wgrad_queue)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.orig_flush()
+            e.record()
+            self.rec.append(("gemm_split3_wgrad_grouped", s, e, flops))
+            self.grouped_problems = n
+        _native.wgrad_flush = flush
 
     def _wrap(self, name):
         fn = self.orig[name]
@@ -248,6 +264,7 @@ class GemmProbe:
     def restore(self):
         for n in self.NAMES:
             setattr(_native, n, self.orig[n])
+        _native.wgrad_flush = self.orig_flush
 
     def summary(self):
         out = {"bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -263,6 +280,8 @@ class GemmProbe:
         tot_fl = sum(d[2] for d in by.values())
         for name, (n, ms, fl) in by.items():
             out[name] = {"launches_per_step": n, "ms_per_step": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 1)}
+        if "gemm_split3_wgrad_grouped" in out:
+            out["gemm_split3_wgrad_grouped"]["layers_per_launch"] = getattr(self, "grouped_problems", None)
         if tot_ms > 0:
             out.update({"ms_per_step": round(tot_ms, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                         "executed": round(6 * tot_fl / (tot_ms * 1e-3) / 1e12, 1),

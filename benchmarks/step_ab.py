@@ -1,7 +1,7 @@
 """A/B of run-time switches on the WHOLE bs = 32 train step in one process, interleaved rounds (one box, one model, one
 optimizer state: the rows are comparable to ~0.1 ms).  Each row flips ONE switch away from the shipped default.
 
-    python benchmarks/step_ab.py [rounds] [steps per round]
+    python benchmarks/step_ab.py [rounds] [steps per round] [adapointr|img|seg]
 """
 import os
 import sys
@@ -23,15 +23,33 @@ from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    which = sys.argv[3] if len(sys.argv) > 3 else "adapointr"          # adapointr | img | seg (bench.py --model)
     device = torch.device("cuda", 0)
     _native.load()
     enable_tuned_gemm()
-    cfg = bench.load_cfg()
+    spec = bench.MODELS[which]
+    cfg = bench.load_cfg(which)
     torch.manual_seed(0)
-    model = build_model_from_cfg(cfg.model).to(device).train()
-    step = runner.TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
-    partial = (torch.rand(bench.BATCH, bench.N_PARTIAL, 3) - 0.5).to(device)
-    gt = (torch.rand(bench.BATCH, bench.N_GT, 3) - 0.5).to(device)
+    model = build_model_from_cfg(cfg.model).to(device)
+    if spec["cls"]:
+        for p in model.base_model.segmentator.parameters():
+            p.requires_grad = False
+    model.train()
+    train = runner.TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
+    B = spec["batch"]
+    partial = (torch.rand(B, bench.N_PARTIAL, 3) - 0.5).to(device)
+    gt = (torch.rand(B, bench.N_GT, 3) - 0.5).to(device)
+    extra = []
+    if spec["img"]:
+        extra.append(torch.rand(B, 3, 224, 224).to(device))
+    if spec["cls"]:
+        cls_vec = torch.zeros(B, 16)
+        cls_vec[torch.arange(B), torch.tensor([0, 4, 8, 15])[torch.arange(B) % 4]] = 1.0
+        extra.append(cls_vec.to(device))
+    extra = tuple(extra)
+
+    def step(p, g):
+        return train(p, g, extra)
 
     def opt(name, value):
         return (lambda: _native.set_option(name, value), lambda: _native.set_option(name, 0))

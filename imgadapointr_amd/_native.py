@@ -53,6 +53,8 @@ def _declare(lib):
         "ptops_edge_group_backward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
         "ptops_gather_max_forward": (c_int, [P, P] + [c_int] * 5 + [P, P, P]),
         "ptops_gather_max_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_gather_max_act_forward": (c_int, [P, P, P, ctypes.c_float] + [c_int] * 5 + [P, P, P]),
+        "ptops_gather_max_act_backward": (c_int, [P, P, P, ctypes.c_float] + [c_int] * 4 + [P, P, P]),
         "ptops_emd_forward": (c_int, [P, P, c_int, c_int, c_int] + [P] * 12 + [ctypes.c_float, c_int, P]),
         "ptops_emd_backward": (c_int, [P] * 5 + [c_int] * 3 + [P]),
         "ptops_edge_select_blocks": (c_int, [c_int]),
@@ -114,7 +116,7 @@ EXPORTS = (
     "ptops_furthest_point_sample",
     "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
-    "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_emd_forward", "ptops_emd_backward",
+    "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_gather_max_act_forward", "ptops_gather_max_act_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
     "ptops_attention_backward_fused", "ptops_colsum_workspace_bytes", "ptops_colsum",
     "ptops_fold_defer", "ptops_fold_flush", "ptops_set_option", "ptops_get_option", "ptops_adamw_row_bytes", "ptops_adamw_chunk_elements", "ptops_adamw_clip_step",
@@ -545,6 +547,39 @@ def gather_max_backward(grad_out, arg, N):
         _call("ptops_gather_max_backward", _ptr(grad_out), _ptr(arg), B, int(N), C, S, _ptr(g),
               _stream(grad_out))
     return g
+
+
+def gather_max_act_forward(p, idx, add, slope):
+    """p [B,N,C], idx int32 [B,S,k], add [B,S,C] -> (LeakyReLU(max_j p[idx] + add, slope) [B,S,C], arg int32 [B,S,C])."""
+    _check(p, "p", torch.float32, 3)
+    _check(idx, "idx", torch.int32, 3)
+    _check(add, "add", torch.float32, 3)
+    dev = _same_device(p, idx, add)
+    B, N, C = p.shape
+    S, k = idx.shape[1], idx.shape[2]
+    if idx.shape[0] != B or tuple(add.shape) != (B, S, C):
+        raise ValueError("gather_max_act_forward: inconsistent shapes")
+    with torch.cuda.device(dev):
+        out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, S, C), dtype=torch.int32, device=dev)
+        _call("ptops_gather_max_act_forward", _ptr(p), _ptr(idx), _ptr(add), float(slope), B, N, C, S, k, _ptr(out),
+              _ptr(arg), _stream(p))
+    return out, arg
+
+
+def gather_max_act_backward(grad_out, out, arg, slope, N):
+    """-> (grad_p [B,N,C], grad_add [B,S,C]) of gather_max_act_forward; N <= 1024."""
+    _check(grad_out, "grad_out", torch.float32, 3)
+    _check(out, "out", torch.float32, 3)
+    _check(arg, "arg", torch.int32, 3)
+    dev = _same_device(grad_out, out, arg)
+    B, S, C = grad_out.shape
+    with torch.cuda.device(dev):
+        gp = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
+        ga = torch.empty((B, S, C), dtype=torch.float32, device=dev)
+        _call("ptops_gather_max_act_backward", _ptr(grad_out), _ptr(out), _ptr(arg), float(slope), B, int(N), C, S, _ptr(gp),
+              _ptr(ga), _stream(grad_out))
+    return gp, ga
 
 
 def emd_forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,

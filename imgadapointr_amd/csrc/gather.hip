@@ -205,12 +205,15 @@ __global__ __launch_bounds__(kTPB) void edge_group_bwd_generic_kernel(
 // Neighbour half of DynamicGraphAttention (models/Transformer_utils.py:811-817) after the
 // linear split: out[b,s,c] = max_j p[b, idx[b,s,j], c]; consecutive lanes own consecutive
 // float4 channel groups of one (b,s), so every neighbour row is read as one coalesced burst.
-template <int V>
+// ACT: out = LeakyReLU(max + add[b,s,c]) - the query half and the activation of DynamicGraphAttention in the same pass
+template <int V, bool ACT = false>
 __global__ __launch_bounds__(kTPB) void gather_max_fwd_kernel(const float* __restrict__ p,
                                                               const int32_t* __restrict__ idx, int N, int C,
                                                               int S, int k, long long total_vec,
                                                               float* __restrict__ out,
-                                                              int32_t* __restrict__ arg) {
+                                                              int32_t* __restrict__ arg,
+                                                              const float* __restrict__ add = nullptr,
+                                                              float slope = 0.f) {
   const int CV = C / V;
   for (long long e = blockIdx.x * (long long)kTPB + threadIdx.x; e < total_vec;
        e += (long long)gridDim.x * kTPB) {
@@ -250,6 +253,14 @@ __global__ __launch_bounds__(kTPB) void gather_max_fwd_kernel(const float* __res
     }
     float* o = out + bs * C + (long long)cv * V;
     int32_t* a = arg + bs * C + (long long)cv * V;
+    if (ACT) {
+      const float* q = add + bs * C + (long long)cv * V;
+#pragma unroll
+      for (int t = 0; t < V; ++t) {
+        const float v = best[t] + q[t];
+        best[t] = v > 0.f ? v : v * slope;
+      }
+    }
     if (V == 4) {
       *reinterpret_cast<float4*>(o) = make_float4(best[0], best[1 % V], best[2 % V], best[3 % V]);
       *reinterpret_cast<int4*>(a) = make_int4(bi[0], bi[1 % V], bi[2 % V], bi[3 % V]);
@@ -280,9 +291,15 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_kernel(const float* __res
 // accumulation error far below the fp32 rounding of the sum itself.  No global atomics, no memset, N <= 1024.
 constexpr int kGmCT = 16;
 
+// ACT: grad_out is the gradient of LeakyReLU(max + add); `out` is that result; the gradient through the activation,
+// g' = out > 0 ? g : g * slope (aten's leaky_relu_backward), is scattered and also written to grad_add.
+template <bool ACT>
 __global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* __restrict__ grad_out,
                                                                   const int32_t* __restrict__ arg, int N, int C,
-                                                                  int S, float* __restrict__ grad_p) {
+                                                                  int S, float* __restrict__ grad_p,
+                                                                  const float* __restrict__ out = nullptr,
+                                                                  float slope = 0.f,
+                                                                  float* __restrict__ grad_add = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long gm_tile[];  // [kGmCT][N + 1]
   __shared__ float wmax[kTPB / 64];
   const int b = blockIdx.y, c0 = blockIdx.x * kGmCT;
@@ -294,7 +311,10 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* _
   int bad = 0;                                               // a NaN or infinity in the slice
   if (c < C)
     for (int s = sl; s < S; s += kTPB / kGmCT) {
-      const float a = fabsf(grad_out[((long long)b * S + s) * C + c]);
+      const long long e = ((long long)b * S + s) * C + c;
+      float g = grad_out[e];
+      if (ACT) g = out[e] > 0.f ? g : g * slope;
+      const float a = fabsf(g);
       const bool fin = a < INFINITY;
       mx = fin ? fmaxf(mx, a) : mx;
       bad |= !fin;
@@ -312,7 +332,11 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* _
   if (c < C) {
     for (int s = sl; s < S; s += kTPB / kGmCT) {
       const long long e = ((long long)b * S + s) * C + c;
-      const float g = grad_out[e];
+      float g = grad_out[e];
+      if (ACT) {
+        g = out[e] > 0.f ? g : g * slope;
+        grad_add[e] = g;
+      }
       const long long q = fabsf(g) < INFINITY ? __double2ll_rn((double)g * scale) : 0ll;
       atomicAdd(&gm_tile[ct * ld + arg[e]], (unsigned long long)q);
     }
@@ -328,7 +352,8 @@ __global__ __launch_bounds__(kTPB) void gather_max_bwd_lds_kernel(const float* _
     if (c < C)
       for (int s = sl; s < S; s += kTPB / kGmCT) {
         const long long e = ((long long)b * S + s) * C + c;
-        const float g = grad_out[e];
+        float g = grad_out[e];
+        if (ACT) g = out[e] > 0.f ? g : g * slope;
         if (!(fabsf(g) < INFINITY)) atomicAdd(&grad_p[((long long)b * N + arg[e]) * C + c], g);
       }
   }
@@ -462,13 +487,55 @@ PTOPS_API int ptops_gather_max_forward(const float* p, const int32_t* idx, int B
   PTOPS_REQUIRE(p && idx && out && arg, "gather_max_forward: null pointer");
   if (C % 4 == 0 && aligned16(p) && aligned16(out) && aligned16(arg)) {
     const long long tv = total / 4;
-    hipLaunchKernelGGL(gather_max_fwd_kernel<4>, dim3(grid_for(tv)), dim3(kTPB), 0, stream, p, idx, N, C, S,
-                       k, tv, out, arg);
+    hipLaunchKernelGGL((gather_max_fwd_kernel<4, false>), dim3(grid_for(tv)), dim3(kTPB), 0, stream, p, idx, N, C, S,
+                       k, tv, out, arg, (const float*)nullptr, 0.f);
   } else {
-    hipLaunchKernelGGL(gather_max_fwd_kernel<1>, dim3(grid_for(total)), dim3(kTPB), 0, stream, p, idx, N, C,
-                       S, k, total, out, arg);
+    hipLaunchKernelGGL((gather_max_fwd_kernel<1, false>), dim3(grid_for(total)), dim3(kTPB), 0, stream, p, idx, N, C,
+                       S, k, total, out, arg, (const float*)nullptr, 0.f);
   }
   return ptops::check_launch("gather_max_fwd_kernel");
+}
+
+// out = LeakyReLU(max_j p[b, idx[b,s,j], :] + add[b,s,:], slope): the whole neighbour aggregation of
+// DynamicGraphAttention after the linear split (models/Transformer_utils.py:811-817) in one launch.
+PTOPS_API int ptops_gather_max_act_forward(const float* p, const int32_t* idx, const float* add, float slope, int B, int N,
+                                           int C, int S, int k, float* out, int32_t* arg, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && N >= 1 && C >= 1 && S >= 0 && k >= 1, "gather_max_act_forward: bad size");
+  const long long total = (long long)B * S * C;
+  if (total == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(p && idx && add && out && arg, "gather_max_act_forward: null pointer");
+  if (C % 4 == 0 && aligned16(p) && aligned16(out) && aligned16(arg)) {
+    const long long tv = total / 4;
+    hipLaunchKernelGGL((gather_max_fwd_kernel<4, true>), dim3(grid_for(tv)), dim3(kTPB), 0, stream, p, idx, N, C, S, k, tv,
+                       out, arg, add, slope);
+  } else {
+    hipLaunchKernelGGL((gather_max_fwd_kernel<1, true>), dim3(grid_for(total)), dim3(kTPB), 0, stream, p, idx, N, C, S, k,
+                       total, out, arg, add, slope);
+  }
+  return ptops::check_launch("gather_max_fwd_kernel");
+}
+
+// Backward of the above: g' = out > 0 ? g : g * slope -> grad_add [B,S,C]; grad_p [B,N,C] = scatter of g' by arg
+// (deterministic fixed-point tile).  N <= 1024 (PTOPS_EINVAL otherwise: use the separate steps).
+PTOPS_API int ptops_gather_max_act_backward(const float* grad_out, const float* out, const int32_t* arg, float slope, int B,
+                                            int N, int C, int S, float* grad_p, float* grad_add, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PTOPS_REQUIRE(B >= 0 && N >= 1 && C >= 1 && S >= 0, "gather_max_act_backward: bad size");
+  PTOPS_REQUIRE(N <= 1024 && B <= 65535, "gather_max_act_backward: at most 1024 source rows and 65535 clouds (N=%d B=%d)", N, B);
+  if (B == 0) return PTOPS_OK;
+  PTOPS_REQUIRE(grad_p, "gather_max_act_backward: null pointer");
+  if ((long long)B * S * C == 0) {
+    (void)ptops::fill_async(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);
+    return ptops::check_launch("gather_max_act_backward(memset)");
+  }
+  PTOPS_REQUIRE(grad_out && out && arg && grad_add, "gather_max_act_backward: null pointer");
+  const size_t lds = sizeof(unsigned long long) * (size_t)kGmCT * (N + 1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kGmCT * 1025));
+  hipLaunchKernelGGL(gather_max_bwd_lds_kernel<true>, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out, arg,
+                     N, C, S, grad_p, out, slope, grad_add);
+  return ptops::check_launch("gather_max_bwd_lds_kernel");
 }
 
 PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* arg, int B, int N, int C,
@@ -481,10 +548,10 @@ PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* ar
   if (total > 0 && N <= 1024 && B <= 65535) {
     PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
     const size_t lds = sizeof(unsigned long long) * (size_t)kGmCT * (N + 1);   // <= 131 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kGmCT * 1025));
-    hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out,
-                       arg, N, C, S, grad_p);
+    hipLaunchKernelGGL(gather_max_bwd_lds_kernel<false>, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out,
+                       arg, N, C, S, grad_p, (const float*)nullptr, 0.f, (float*)nullptr);
     return ptops::check_launch("gather_max_bwd_lds_kernel");
   }
   (void)ptops::fill_async(grad_p, 0, sizeof(float) * (size_t)B * N * C, stream);

@@ -8,6 +8,7 @@ reductions ChamferDistanceL2 / L2_split / L1 / L1_PM (__init__.py:28-103), inclu
 `ignore_zeros` rule (rows whose coordinate SUM is zero are dropped when the batch is 1).
 The kernels are imgadapointr_amd/csrc/chamfer.hip.
 """
+import os
 import types
 
 import torch
@@ -43,7 +44,7 @@ class ChamferFunction(torch.autograd.Function):
 # `ptops_chamfer_reduce`), instead of the six (forward) + seven (backward) element-wise launches of the literal
 # torch.mean / torch.sqrt chain below.  Same values: the backward uses autograd's formulas in autograd's order, the
 # forward sums in another (fixed) order than torch.mean.
-FUSED_REDUCTIONS = True
+FUSED_REDUCTIONS = os.environ.get("PTOPS_FUSED_CHAMFER_REDUCTIONS", "1") != "0"
 
 _SQRT = {"L2": False, "L2_split": False, "L1": True, "L1_PM": True}
 _WHICH = {"L2": 2, "L2_split": 0, "L1": 3, "L1_PM": 0}

@@ -469,6 +469,35 @@ class _GatherMax(torch.autograd.Function):
         return _native.gather_max_backward(grad_out.contiguous(), arg, ctx.N), None
 
 
+class _GatherMaxAct(torch.autograd.Function):
+    """LeakyReLU(max_j p[idx] + add, slope) in one launch each way (csrc/gather.hip); values and gradients are those of
+    the three separate ops (same float operations in the same order; the scatter is the deterministic tile)."""
+
+    @staticmethod
+    def forward(ctx, p, idx, add, slope):
+        out, arg = _native.gather_max_act_forward(p, idx, add, slope)
+        ctx.save_for_backward(out, arg)
+        ctx.N, ctx.slope = p.size(1), slope
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        out, arg = ctx.saved_tensors
+        gp, ga = _native.gather_max_act_backward(grad_out.contiguous(), out, arg, ctx.slope, ctx.N)
+        return gp, None, ga, None
+
+
+FUSED_GATHER_MAX_ACT = os.environ.get("PTOPS_FUSED_GATHER_MAX_ACT", "1") != "0"
+
+
+def gather_max_add_leaky_relu(p, idx, add, slope):
+    """leaky_relu(gather_max(p, idx) + add, slope)."""
+    if (FUSED_GATHER_MAX_ACT and p.is_cuda and p.dtype == torch.float32 and add.dtype == torch.float32 and p.size(1) <= 1024
+            and p.size(0) <= 65535 and _native.backend_for_testing() is None and add.shape[:2] == idx.shape[:2]):
+        return _GatherMaxAct.apply(p.contiguous(), idx.contiguous(), add.contiguous(), float(slope))
+    return F.leaky_relu(gather_max(p, idx) + add, slope)
+
+
 def gather_max(p, idx):
     """p [B,N,C], idx int32 [B,S,k] -> max over the k gathered rows, [B,S,C]."""
     return _GatherMax.apply(p.contiguous(), idx.contiguous())[0]
@@ -767,7 +796,7 @@ class DynamicGraphAttention(nn.Module):
             w1, w21 = _SplitEdgeWeight.apply(lin.weight)
             p = F.linear(v, w1)                    # per source token
             qt = F.linear(q, w21, lin.bias)        # per query token
-            return F.leaky_relu(gather_max(p, idx) + qt, 0.2)
+            return gather_max_add_leaky_relu(p, idx, qt, self.knn_map[1].negative_slope)
         local_v = index_points(v, idx)             # [B,S,k,C]
         qe = q.unsqueeze(-2).expand(-1, -1, idx.size(-1), -1)
         feature = torch.cat((local_v - qe, qe), dim=-1)

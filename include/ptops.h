@@ -161,6 +161,15 @@ int ptops_gather_max_forward(const float* p, const int32_t* idx, int B, int N, i
 int ptops_gather_max_backward(const float* grad_out, const int32_t* arg, int B, int N,
                               int C, int S, float* grad_p, void* stream);
 
+/* The same aggregation with the query half and the activation of DynamicGraphAttention folded in:
+ * out = LeakyReLU(max_j p[b, idx[b,s,j], :] + add[b,s,:], slope)  (Transformer_utils.py:811-817 after the linear split:
+ * the `+ q-term` and nn.LeakyReLU(0.2) that follow the max).  Backward: g' = out > 0 ? g : g * slope (aten's
+ * leaky_relu_backward) goes to grad_add [B,S,C] and, scattered by arg, to grad_p [B,N,C] (deterministic; N <= 1024). */
+int ptops_gather_max_act_forward(const float* p, const int32_t* idx, const float* add, float slope, int B, int N, int C,
+                                 int S, int k, float* out, int32_t* arg, void* stream);
+int ptops_gather_max_act_backward(const float* grad_out, const float* out, const int32_t* arg, float slope, int B, int N,
+                                  int C, int S, float* grad_p, float* grad_add, void* stream);
+
 /* --------------------------------------------------------------------- EMD --
  * Replaces emd.forward / emd.backward (extensions/emd/emd.cpp:6-31, kernels
  * extensions/emd/emd_cuda.cu:23-316).  Same caller-allocates contract as the

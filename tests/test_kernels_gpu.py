@@ -583,6 +583,36 @@ def test_gemm_split3_wgrad_and_bias_gradient(native, M, N, K):
             native.gemm_split3_wgrad(dy[:M - 8], x[:M - 8])             # M % 16 != 0
 
 
+@pytest.mark.parametrize("B,N,S,C,k", [(32, 640, 640, 384, 8), (3, 256, 100, 384, 10), (2, 77, 50, 6, 5)])
+def test_gather_max_act_equals_the_three_ops(native, B, N, S, C, k):
+    """LeakyReLU(max_j p[idx] + add) in one launch each way (`ptops_gather_max_act_*`) against gather_max, `+` and
+    F.leaky_relu as separate ops: outputs and all gradients bit for bit (the same float operations; exact zeros of the
+    pre-activation take the slope branch in both)."""
+    from imgadapointr_amd.models import Transformer_utils as TU
+    torch.manual_seed(B + N + C)
+    p0 = torch.randn(B, N, C, device="cuda")
+    add0 = torch.randn(B, S, C, device="cuda")
+    idx = torch.randint(0, N, (B, S, k), device="cuda", dtype=torch.int32)
+    add0[0, 0, :] = -p0[0].index_select(0, idx[0, 0].long()).max(0).values            # pre-activation exactly 0
+    w = torch.randn(B, S, C, device="cuda")
+    res = {}
+    for fused in (True, False):
+        TU.FUSED_GATHER_MAX_ACT = fused
+        try:
+            p, add = p0.clone().requires_grad_(True), add0.clone().requires_grad_(True)
+            out = TU.gather_max_add_leaky_relu(p, idx, add, 0.2)
+            (out * w).sum().backward()
+            res[fused] = (out.detach(), p.grad, add.grad)
+        finally:
+            TU.FUSED_GATHER_MAX_ACT = True
+    assert float(res[True][0][0, 0].abs().max()) == 0.0
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    with pytest.raises(native.PtopsError):
+        native.gather_max_act_backward(torch.zeros(1, 4, 4, device="cuda"), torch.zeros(1, 4, 4, device="cuda"),
+                                       torch.zeros(1, 4, 4, device="cuda", dtype=torch.int32), 0.2, 2000)
+
+
 def test_grouped_weight_gradients(native):
     """`ptops_gemm_f32_split3_wgrad_grouped`: the dW / db of a ragged mix of layers (tiles that do not fill 128 x 128,
     contractions that do not divide into equal jobs, row-sliced operands, with and without db, a one-job problem) from ONE
