@@ -161,8 +161,40 @@ def backend_for_testing():
     return _test_backend
 
 
+class _on:
+    """`with torch.cuda.device(dev)` without the per-use argument parsing (two C calls; the wrappers below run ~550
+    times per train step)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index if dev.index is not None else -1
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_exchangeDevice(self.idx) if self.idx >= 0 else -1
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch._C._cuda_maybeExchangeDevice(self.prev)
+        return False
+
+
+class _RawStream:
+    """The current HIP stream of a device as its raw handle (`.cuda_stream`, like torch.cuda.Stream): one C call instead
+    of building a torch.cuda.Stream object per kernel launch (2.7 us each, 550 times per train step)."""
+    __slots__ = ("cuda_stream",)
+
+    def __init__(self, handle):
+        self.cuda_stream = handle
+
+
+def _current_stream(dev=None):
+    idx = dev.index if (dev is not None and dev.index is not None) else torch.cuda.current_device()
+    return _RawStream(torch._C._cuda_getCurrentRawStream(idx))
+
+
 def _stream(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(_current_stream(t.device).cuda_stream)
 
 
 def _check(t, name, dtype, ndim):
@@ -184,11 +216,16 @@ def _ptr(t):
     return t if isinstance(t, ctypes.c_void_p) else ctypes.c_void_p(t.data_ptr())
 
 
+_entry_points = {}
+
+
 def _call(fn_name, *args):
-    lib = load()
-    rc = getattr(lib, fn_name)(*args)
+    fn = _entry_points.get(fn_name)
+    if fn is None:
+        fn = _entry_points[fn_name] = getattr(load(), fn_name)
+    rc = fn(*args)
     if rc != 0:
-        raise PtopsError(f"{fn_name} failed ({rc}): {lib.ptops_last_error().decode()}")
+        raise PtopsError(f"{fn_name} failed ({rc}): {load().ptops_last_error().decode()}")
 
 
 def _same_device(*ts):
@@ -292,7 +329,7 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
         raise ValueError(f"chamfer_forward: expected [B,n,3] and [B,m,3], got {tuple(xyz1.shape)} {tuple(xyz2.shape)}")
     lib = load()
     algos = list(algorithm) if isinstance(algorithm, (tuple, list)) else [algorithm, algorithm]
-    with torch.cuda.device(dev):
+    with _on(dev):
         dist1 = torch.empty((B, n), dtype=torch.float32, device=dev)
         dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
         idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
@@ -327,8 +364,8 @@ def chamfer_reduce(dist1, dist2, take_sqrt):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise ValueError(f"chamfer_reduce: {name} must be a contiguous float32 tensor")
     n1, n2 = dist1.numel(), dist2.numel()
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         need = int(load().ptops_chamfer_reduce_workspace_bytes(n1, n2))
         key = (dev.index, stream.cuda_stream)
         ws = _chamfer_reduce_ws.get(key)
@@ -345,7 +382,7 @@ def chamfer_reduce_backward(dist1, dist2, take_sqrt, which, go1, go2=None):
     """Gradients of dist1 / dist2 for the gradient of one output of `chamfer_reduce`: `which` 2 / 3 -> of out[2] / out[3]
     (go1, a one-element tensor), 0 -> of out[0] and out[1] (go1, go2; None = no gradient)."""
     dev = _same_device(dist1, dist2)
-    with torch.cuda.device(dev):
+    with _on(dev):
         g1, g2 = torch.empty_like(dist1), torch.empty_like(dist2)
         _call("ptops_chamfer_reduce_backward", _ptr(dist1), dist1.numel(), _ptr(dist2), dist2.numel(), int(bool(take_sqrt)),
               int(which), _ptr(go1) if go1 is not None else None, _ptr(go2) if go2 is not None else None, _ptr(g1), _ptr(g2),
@@ -375,12 +412,12 @@ def chamfer_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2, determinist
     if tuple(idx1.shape) != (B, n) or tuple(idx2.shape) != (B, m) or \
             tuple(grad_dist1.shape) != (B, n) or tuple(grad_dist2.shape) != (B, m):
         raise ValueError("chamfer_backward: idx/grad shapes do not match the clouds")
-    with torch.cuda.device(dev):
+    with _on(dev):
         g1 = torch.empty_like(xyz1)
         g2 = torch.empty_like(xyz2)
         det = DETERMINISTIC_BACKWARD if deterministic is None else deterministic
         if det and B > 0 and 0 < n <= 16384 and 0 < m <= 16384:
-            stream = torch.cuda.current_stream(dev)
+            stream = _current_stream(dev)
             need = load().ptops_chamfer_backward_det_workspace_bytes(B, n, m)
             ws = _scratch(dev, stream, need)
             _call("ptops_chamfer_backward_det", _ptr(xyz1), _ptr(xyz2), _ptr(idx1), _ptr(idx2), _ptr(grad_dist1),
@@ -400,7 +437,7 @@ def furthest_point_sample(xyz, npoint):
     B, N, c = xyz.shape
     if c != 3:
         raise ValueError(f"furthest_point_sample: expected [B,N,3], got {tuple(xyz.shape)}")
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         idx = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
         _call("ptops_furthest_point_sample", _ptr(xyz), B, N, int(npoint), _ptr(idx), _stream(xyz))
     return idx
@@ -415,7 +452,7 @@ def gather_forward(feat, idx):
     dev = _same_device(feat, idx)
     B, C, N = feat.shape
     npoint = idx.shape[1]
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, C, npoint), dtype=torch.float32, device=dev)
         _call("ptops_gather_forward", _ptr(feat), _ptr(idx), B, C, N, npoint, _ptr(out), _stream(feat))
     return out
@@ -428,7 +465,7 @@ def gather_backward(grad_out, idx, N):
     _check(idx, "idx", torch.int32, 2)
     dev = _same_device(grad_out, idx)
     B, C, npoint = grad_out.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = torch.empty((B, C, int(N)), dtype=torch.float32, device=dev)
         _call("ptops_gather_backward", _ptr(grad_out), _ptr(idx), B, C, int(N), npoint, _ptr(g),
               _stream(grad_out))
@@ -446,7 +483,7 @@ def knn(k, xyz, new_xyz):
     B2, S, c2 = new_xyz.shape
     if c != 3 or c2 != 3 or B != B2:
         raise ValueError(f"knn: expected [B,N,3] and [B,S,3], got {tuple(xyz.shape)} {tuple(new_xyz.shape)}")
-    with torch.cuda.device(dev):
+    with _on(dev):
         idx = torch.empty((B, S, int(k)), dtype=torch.int32, device=dev)
         _call("ptops_knn", _ptr(xyz), _ptr(new_xyz), B, N, S, int(k), _ptr(idx), _stream(xyz))
     return idx
@@ -461,7 +498,7 @@ def index_points_forward(points, idx):
     dev = _same_device(points, idx)
     B, N, C = points.shape
     _, S, k = idx.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, S, k, C), dtype=torch.float32, device=dev)
         _call("ptops_index_points_forward", _ptr(points), _ptr(idx), B, N, C, S, k, _ptr(out),
               _stream(points))
@@ -475,7 +512,7 @@ def index_points_backward(grad_out, idx, N):
     _check(idx, "idx", torch.int32, 3)
     dev = _same_device(grad_out, idx)
     B, S, k, C = grad_out.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
         _call("ptops_index_points_backward", _ptr(grad_out), _ptr(idx), B, int(N), C, S, k, _ptr(g),
               _stream(grad_out))
@@ -495,7 +532,7 @@ def edge_group_forward(x_k, x_q, idx):
     k = idx.shape[2]
     if tuple(x_q.shape[:2]) != (B, C) or tuple(idx.shape[:2]) != (B, Nq):
         raise ValueError("edge_group_forward: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, 2 * C, Nq, k), dtype=torch.float32, device=dev)
         _call("ptops_edge_group_forward", _ptr(x_k), _ptr(x_q), _ptr(idx), B, C, Nk, Nq, k, _ptr(out),
               _stream(x_k))
@@ -510,7 +547,7 @@ def edge_group_backward(grad_out, idx, Nk):
     dev = _same_device(grad_out, idx)
     B, C2, Nq, k = grad_out.shape
     C = C2 // 2
-    with torch.cuda.device(dev):
+    with _on(dev):
         gk = torch.empty((B, C, int(Nk)), dtype=torch.float32, device=dev)
         gq = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
         _call("ptops_edge_group_backward", _ptr(grad_out), _ptr(idx), B, C, int(Nk), Nq, k, _ptr(gk),
@@ -527,7 +564,7 @@ def gather_max_forward(p, idx):
     dev = _same_device(p, idx)
     B, N, C = p.shape
     _, S, k = idx.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
         arg = torch.empty((B, S, C), dtype=torch.int32, device=dev)
         _call("ptops_gather_max_forward", _ptr(p), _ptr(idx), B, N, C, S, k, _ptr(out), _ptr(arg),
@@ -542,7 +579,7 @@ def gather_max_backward(grad_out, arg, N):
     _check(arg, "arg", torch.int32, 3)
     dev = _same_device(grad_out, arg)
     B, S, C = grad_out.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         g = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
         _call("ptops_gather_max_backward", _ptr(grad_out), _ptr(arg), B, int(N), C, S, _ptr(g),
               _stream(grad_out))
@@ -559,7 +596,7 @@ def gather_max_act_forward(p, idx, add, slope):
     S, k = idx.shape[1], idx.shape[2]
     if idx.shape[0] != B or tuple(add.shape) != (B, S, C):
         raise ValueError("gather_max_act_forward: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
         arg = torch.empty((B, S, C), dtype=torch.int32, device=dev)
         _call("ptops_gather_max_act_forward", _ptr(p), _ptr(idx), _ptr(add), float(slope), B, N, C, S, k, _ptr(out),
@@ -574,7 +611,7 @@ def gather_max_act_backward(grad_out, out, arg, slope, N):
     _check(arg, "arg", torch.int32, 3)
     dev = _same_device(grad_out, out, arg)
     B, S, C = grad_out.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         gp = torch.empty((B, int(N), C), dtype=torch.float32, device=dev)
         ga = torch.empty((B, S, C), dtype=torch.float32, device=dev)
         _call("ptops_gather_max_act_backward", _ptr(grad_out), _ptr(out), _ptr(arg), float(slope), B, int(N), C, S, _ptr(gp),
@@ -606,7 +643,7 @@ def emd_forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_in
             raise ValueError(f"emd_forward: {name} has {t.numel()} elements, needs {numel}")
     _same_device(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
                  unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx)
-    with torch.cuda.device(xyz1.device):
+    with _on(xyz1.device):
         _call("ptops_emd_forward", _ptr(xyz1), _ptr(xyz2), B, n, m, _ptr(dist), _ptr(assignment), _ptr(price),
               _ptr(assignment_inv), _ptr(bid), _ptr(bid_increments), _ptr(max_increments), _ptr(unass_idx),
               _ptr(unass_cnt), _ptr(unass_cnt_sum), _ptr(cnt_tmp), _ptr(max_idx), ctypes.c_float(float(eps)),
@@ -625,7 +662,7 @@ def emd_backward(xyz1, xyz2, gradxyz, graddist, idx):
     _check(idx, "idx", torch.int32, 2)
     _same_device(xyz1, xyz2, gradxyz, graddist, idx)
     B, n, _ = xyz1.shape
-    with torch.cuda.device(xyz1.device):
+    with _on(xyz1.device):
         _call("ptops_emd_backward", _ptr(xyz1), _ptr(xyz2), _ptr(gradxyz), _ptr(graddist), _ptr(idx), B, n,
               xyz2.shape[1], _stream(xyz1))
     return 1
@@ -657,7 +694,7 @@ def attention_forward(q, k, v, split_q, limit_k, scale):
     dev = _same_device(q, k, v)
     B, H, Nq, _ = q.shape
     Nk = k.size(2)
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, Nq, H, 64), dtype=torch.float32, device=dev)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=dev)
         _call("ptops_attention_forward", _ptr(q), _ptr(k), _ptr(v), B, H, Nq, Nk, qs, ks, vs, int(split_q),
@@ -680,9 +717,9 @@ def attention_backward(q, k, v, out, dout, lse, split_q, limit_k, scale, dq, dk,
         raise ValueError("attention_backward: gradient views must have the shapes of q / k / v")
     if not (out.is_contiguous() and dout.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attention_backward: out, dout and lse must be contiguous")
-    with torch.cuda.device(dev):
+    with _on(dev):
         if fused:
-            stream = torch.cuda.current_stream(dev)
+            stream = _current_stream(dev)
             ws = _scratch(dev, stream, max(load().ptops_attention_backward_fused_workspace_bytes(B, H, Nq, Nk), 16))
             _call("ptops_attention_backward_fused", _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), B, H, Nq,
                   Nk, qs, ks, vs, dqs, dks, dvs, int(split_q), int(limit_k), ctypes.c_float(float(scale)), _ptr(dq),
@@ -729,7 +766,7 @@ class deferred_folds:
             dev = self.device
             if dev is None:
                 dev = torch.device("cuda", torch.cuda.current_device())
-            handle = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            handle = ctypes.c_void_p(_current_stream(dev).cuda_stream)
             load().ptops_fold_defer(handle, 2 if FOLD_POISON else 1)
             _fold_deferred, _fold_stream = True, (dev, handle)
         return self
@@ -768,8 +805,8 @@ def fold_flush():
     wgrad_flush()
     if _fold_keepalive:
         dev = _fold_keepalive[0].device
-        with torch.cuda.device(dev):
-            handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with _on(dev):
+            handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(_current_stream(dev).cuda_stream)
             _call("ptops_fold_flush", handle)
         _fold_keepalive.clear()
         for slot in _fold_arena.values():               # stream order: the next producers write after this flush
@@ -808,8 +845,8 @@ def colsum(x):
         return x.sum(0)
     _check(x, "x", torch.float32, 2)
     M, N = x.shape
-    with torch.cuda.device(x.device):
-        stream = torch.cuda.current_stream(x.device)
+    with _on(x.device):
+        stream = _current_stream(x.device)
         need = max(load().ptops_colsum_workspace_bytes(M, N), 16)
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
         ws = _fold_workspace(x.device, stream, need, out)
@@ -826,7 +863,7 @@ def max_tokens_forward(x):
     """x [B,M,C] float32 contiguous (C % 4 == 0) -> (max over tokens [B,C], arg-max token int32 [B,C])."""
     _check(x, "x", torch.float32, 3)
     B, M, C = x.shape
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         out = torch.empty((B, C), dtype=torch.float32, device=x.device)
         arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
         _call("ptops_max_tokens_forward", _ptr(x), B, M, C, _ptr(out), _ptr(arg), _stream(x))
@@ -839,7 +876,7 @@ def max_tokens_backward(grad_out, arg, M):
     _check(arg, "arg", torch.int32, 2)
     _same_device(grad_out, arg)
     B, C = grad_out.shape
-    with torch.cuda.device(grad_out.device):
+    with _on(grad_out.device):
         gx = torch.empty((B, int(M), C), dtype=torch.float32, device=grad_out.device)
         _call("ptops_max_tokens_backward", _ptr(grad_out), _ptr(arg), B, int(M), C, _ptr(gx), _stream(grad_out))
     return gx
@@ -858,7 +895,7 @@ def gemm_split3(a, b, bias=None, a_k_contiguous=True, b_k_contiguous=True, out=N
     N, K2 = (b.shape[0], b.shape[1]) if b_k_contiguous else (b.shape[1], b.shape[0])
     if K != K2:
         raise ValueError(f"gemm_split3: inner sizes differ ({K} vs {K2})")
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         if bias is not None:
@@ -878,7 +915,7 @@ def gemm_split3_gelu(x, w, bias=None):
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"gemm_split3_gelu: inner sizes differ ({K} vs {w.shape[1]})")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         u = torch.empty((M, N), dtype=torch.float32, device=x.device)
         g = torch.empty((M, N), dtype=torch.float32, device=x.device)
         if bias is not None:
@@ -899,7 +936,7 @@ def gemm_split3_wgrad(dy, x, want_bias=False):
     if x.shape[0] != M:
         raise ValueError(f"gemm_split3_wgrad: row counts differ ({M} vs {x.shape[0]})")
     K = x.shape[1]
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
         db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
         need = int(load().ptops_gemm_f32_split3_wgrad_workspace(M, N, K))
@@ -923,7 +960,7 @@ def wgrad_deferrable(dy, x):
     return (GROUPED_WGRAD and _fold_deferred and _test_backend is None and dy.is_cuda and dy.dtype == torch.float32
             and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1
             and dy.size(0) == x.size(0) and dy.size(0) >= 16 and dy.size(0) % 16 == 0 and x.size(1) % 4 == 0
-            and dy.device == _fold_stream[0] and torch.cuda.current_stream(dy.device).cuda_stream == (_fold_stream[1].value or 0))
+            and dy.device == _fold_stream[0] and _current_stream(dy.device).cuda_stream == (_fold_stream[1].value or 0))
 
 
 def wgrad_defer(dy, x, want_bias):
@@ -956,8 +993,8 @@ def wgrad_flush():
     dev = queue[0][0].device
     n = len(queue)
     lib = load()
-    with torch.cuda.device(dev):
-        handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with _on(dev):
+        handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(_current_stream(dev).cuda_stream)
         key = (dev.index, tuple((q[4], q[5], q[6], q[3] != 0) for q in queue))
         plan = _wgrad_plans.get(key)
         if plan is None:
@@ -1006,7 +1043,7 @@ def wgrad_flush():
 
 def adamw_clip_step(rows_dev, n_tensors, chunks_dev, n_chunks, max_norm, beta1, beta2, eps, partial, norm_coef):
     """Gradient-norm clipping + AdamW over the device tables of utils/clip_adamw.py (csrc/optimizer.hip)."""
-    with torch.cuda.device(rows_dev.device):
+    with _on(rows_dev.device):
         _call("ptops_adamw_clip_step", _ptr(rows_dev), int(n_tensors), _ptr(chunks_dev), int(n_chunks), float(max_norm),
               float(beta1), float(beta2), float(eps), _ptr(partial), _ptr(norm_coef), _stream(rows_dev))
 
@@ -1035,7 +1072,7 @@ def layer_norm_forward(x, weight, bias, eps):
     rows, C = x.shape
     if weight.numel() != C or bias.numel() != C:
         raise ValueError("layer_norm_forward: weight / bias must have C elements")
-    with torch.cuda.device(dev):
+    with _on(dev):
         y = torch.empty_like(x)
         mean = torch.empty((rows,), dtype=torch.float32, device=dev)
         rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
@@ -1054,7 +1091,7 @@ def add_layer_norm_forward(x, res, weight, bias, eps):
     rows, C = x.shape
     if tuple(res.shape) != (rows, C) or weight.numel() != C or bias.numel() != C:
         raise ValueError("add_layer_norm_forward: inconsistent shapes")
-    with torch.cuda.device(dev):
+    with _on(dev):
         s = torch.empty_like(x)
         y = torch.empty_like(x)
         mean = torch.empty((rows,), dtype=torch.float32, device=dev)
@@ -1079,8 +1116,8 @@ def layer_norm_backward(dy, x, mean, rstd, weight, extra=None):
         _check(extra, "extra", torch.float32, 2)
         if tuple(extra.shape) != (rows, C) or extra.device != dev:
             raise ValueError("layer_norm_backward: extra must match x")
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         dx = torch.empty_like(x)
         dgb = torch.empty((3 * C,), dtype=torch.float32, device=dev)
         ws = _fold_workspace(dev, stream, max(load().ptops_layer_norm_backward_workspace_bytes(rows, C), 16), dgb)
@@ -1098,8 +1135,8 @@ def gelu_backward_colsum(x, dy):
     M, N = x.shape
     if tuple(dy.shape) != (M, N):
         raise ValueError("gelu_backward_colsum: shapes differ")
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         dpre = torch.empty_like(x)
         cs = torch.empty((N,), dtype=torch.float32, device=dev)
         ws = _fold_workspace(dev, stream, max(load().ptops_gelu_backward_colsum_workspace_bytes(M, N), 16), cs)
@@ -1115,8 +1152,8 @@ def batch_norm_rows_forward(x, weight, bias, eps, slope):
     _check(bias, "bias", torch.float32, 1)
     dev = _same_device(x, weight, bias)
     M, N = x.shape
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         ws = _scratch(dev, stream, max(load().ptops_batch_norm_rows_workspace_bytes(M, N), 16))
         y = torch.empty_like(x)
         stats = torch.empty((2 * N,), dtype=torch.float32, device=dev)
@@ -1132,8 +1169,8 @@ def batch_norm_rows_backward(dy, x, stats, weight, bias, slope):
     _check(x, "x", torch.float32, 2)
     dev = _same_device(dy, x, stats, weight, bias)
     M, N = x.shape
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         ws = _scratch(dev, stream, max(load().ptops_batch_norm_rows_workspace_bytes(M, N), 16))
         dx = torch.empty_like(x)
         dbg = torch.empty((2 * N,), dtype=torch.float32, device=dev)
@@ -1155,7 +1192,7 @@ def edge_select(P, R, idx, gamma):
     if tuple(R.shape) != (B, C, Nq) or idx.shape[0] != B or gamma.numel() != C:
         raise ValueError("edge_select: inconsistent shapes")
     nblk = load().ptops_edge_select_blocks(Nq)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ysel = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
         nsel = torch.empty((B, C, Nq), dtype=torch.int32, device=dev)
         ysum = torch.empty((B, C, Nq), dtype=torch.float32, device=dev)
@@ -1173,7 +1210,7 @@ def edge_norm_forward(ysel, partial, gamma, beta, groups, k, eps, slope):
     _check(beta, "beta", torch.float32, 1)
     dev = _same_device(ysel, partial, gamma, beta)
     B, C, Nq = ysel.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty_like(ysel)
         mean_rstd = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
         _call("ptops_edge_norm_forward", _ptr(ysel), _ptr(partial), _ptr(gamma), _ptr(beta), B, C, Nq, partial.size(2),
@@ -1191,8 +1228,8 @@ def edge_norm_backward(grad_out, ysel, ysum, P, R, idx, nsel, gamma, beta, mean_
     dev = _same_device(grad_out, ysel, ysum, P, R, idx, nsel, gamma, beta, mean_rstd)
     B, C, Nq = ysel.shape
     Nk, k, groups = P.size(2), idx.size(2), mean_rstd.size(1)
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev)
+    with _on(dev):
+        stream = _current_stream(dev)
         dP = torch.empty_like(P)
         dR = torch.empty_like(R)
         sums = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
@@ -1213,7 +1250,7 @@ def edge_scatter(dense, sel, idx, nsel, Nk):
     dev = _same_device(dense, sel, idx, nsel)
     B, C, Nq = dense.shape
     k = idx.shape[2]
-    with torch.cuda.device(dev):
+    with _on(dev):
         T = torch.empty((B, C, int(Nk)), dtype=torch.float32, device=dev)
         _call("ptops_edge_scatter", _ptr(dense), _ptr(sel), _ptr(idx), _ptr(nsel), B, C, int(Nk), Nq, k, _ptr(T),
               _stream(dense))

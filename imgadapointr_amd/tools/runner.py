@@ -63,6 +63,7 @@ class TrainStep:
         self.step_per_update = step_per_update
         self.ddp = model if isinstance(model, FlatDDP) else None
         self.params = [p for p in self.net.parameters() if p.requires_grad]
+        self._every_param = list(self.net.parameters())
         self._num_iter = 0
         self.before_update = None       # optional callable(): runs when the gradients of an update are complete
         self.zero_grad()
@@ -71,7 +72,10 @@ class TrainStep:
         if self.ddp is not None:
             self.ddp.zero_grad()
         else:
-            self.net.zero_grad(set_to_none=True)
+            # nn.Module.zero_grad(set_to_none=True) walks the module tree on every call (0.7 ms of host time per step for
+            # the 330 parameters of AdaPoinTr); the parameter list is fixed for the life of this object
+            for p in self._every_param:
+                p.grad = None
 
     def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None):
         """`denoise_noise` ([B,64,3]) replaces the random jitter of the denoise seeds (fixture-driven parity runs)."""
