@@ -1224,6 +1224,58 @@ def test_deferred_folds_guards(native, grouped, monkeypatch):
         native.FOLD_POISON = old
 
 
+def test_deferred_gradients_of_a_reshaped_leaf_weight(native):
+    """`_linear_tokens` on a 1x1 convolution's weight viewed as a matrix (AdaPoinTr.increase_dim): the weight handed to the
+    Linear node is a reshaped VIEW of the leaf, its queued gradient travels back through the view's backward (unsqueeze)
+    and must be adopted unread - checked with poisoned outputs against the immediate path."""
+    from imgadapointr_amd.models.AdaPoinTr import _linear_tokens
+    torch.manual_seed(8)
+    conv = torch.nn.Conv1d(384, 1024, 1).cuda()
+    x = torch.randn(4608, 384, device="cuda", requires_grad=True)
+    w = torch.randn(4608, 1024, device="cuda")
+    res = {}
+    old = native.FOLD_POISON
+    native.FOLD_POISON = True
+    try:
+        for defer in (False, True):
+            conv.zero_grad(set_to_none=True)
+            x.grad = None
+            y = _linear_tokens(x, conv.weight.squeeze(-1), conv.bias)
+            import contextlib
+            with (native.deferred_folds(list(conv.parameters())) if defer else contextlib.nullcontext()):
+                (y * w).sum().backward()
+                queued = len(native._wgrad_queue)
+            assert queued == (1 if defer else 0)
+            res[defer] = [x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()]
+    finally:
+        native.FOLD_POISON = old
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert a.shape == b.shape and _same_gradient(b, a, False)
+
+
+def test_side_stream_fps_equals_the_plain_call(native):
+    """`furthest_point_sample_async` with the side stream switched on returns the indices of the plain call, also when
+    the input was produced on the current stream just before and the result is consumed right after (the two joins)."""
+    from imgadapointr_amd.pointnet2_ops import pointnet2_utils as pu
+    torch.manual_seed(2)
+    base = torch.rand(8, 2048, 3, device="cuda")
+    old = pu.OVERLAP_FPS
+    pu.OVERLAP_FPS = True
+    try:
+        for _ in range(3):
+            xyz = (base * 2.0 - 1.0).contiguous()                    # produced on the current stream
+            h = pu.furthest_point_sample_async(xyz, 512)
+            filler = (xyz @ xyz.transpose(1, 2)).sum()               # main-stream work underneath
+            idx = h.result()
+            picked = pu.gather_operation(xyz.transpose(1, 2).contiguous(), idx)      # consumed at once
+            want = pu.furthest_point_sample(xyz, 512)
+            assert torch.equal(idx, want) and torch.isfinite(filler) and picked.shape == (8, 3, 512)
+            assert h.result() is idx                                 # idempotent
+    finally:
+        pu.OVERLAP_FPS = old
+
+
 def test_clip_adamw_matches_torch(native):
     """ClipAdamW.step_clipped == clip_grad_norm_ + torch.optim.AdamW.step over several steps: two weight-decay groups,
     an lr change, a parameter without gradient on some steps, tensor sizes around the 4096-element chunk, clipping
