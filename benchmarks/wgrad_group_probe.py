@@ -105,6 +105,11 @@ def main():
         print(f"grouped, {target:5d} steps per job      : {t:7.3f} ms   {flops / t / 1e9:6.1f} TFLOP/s   workspace {ws_bytes / 2**20:7.1f} MiB", flush=True)
     _native.set_option("PTOPS_WGRAD_GROUP_STEPS", 0)
     _native._wgrad_plans.clear()
+    for occ3 in (0, 1, 0, 1):
+        _native.set_option("PTOPS_WGRAD_OCC3", occ3)
+        t = timed(grouped, 20)
+        print(f"grouped, default job length, {'three' if occ3 else 'two'} workgroups per CU: {t:7.3f} ms   {flops / t / 1e9:6.1f} TFLOP/s", flush=True)
+    _native.set_option("PTOPS_WGRAD_OCC3", 0)
 
     grouped()
     torch.cuda.synchronize()

@@ -335,7 +335,8 @@ struct WgradRJob {        // 16 bytes: 1024-float chunk `chunk` of dW (kind 0) o
 };
 constexpr int kWgradMagic = 0x57475233;
 
-__global__ __launch_bounds__(512, 2) void gemm_split3_wgrad_grouped_kernel(const WgradProblem* __restrict__ probs,
+template <int OCC>   // waves per SIMD the register budget must allow: 2 = the default (two workgroups per CU need four)
+__global__ __launch_bounds__(512, OCC) void gemm_split3_wgrad_grouped_kernel(const WgradProblem* __restrict__ probs,
                                                                            const WgradPlanProblem* __restrict__ plan,
                                                                            const WgradJob* __restrict__ jobs,
                                                                            float* __restrict__ ws) {
@@ -630,8 +631,12 @@ PTOPS_API int ptops_gemm_f32_split3_wgrad_grouped(const void* problems_host, con
   const WgradPlanProblem* qd = (const WgradPlanProblem*)pd;
   const WgradJob* jobs = (const WgradJob*)(pd + (size_t)n * sizeof(WgradPlanProblem));
   const WgradRJob* rjobs = (const WgradRJob*)((const unsigned char*)jobs + (size_t)h.n_jobs * sizeof(WgradJob));
-  hipLaunchKernelGGL(gemm_split3_wgrad_grouped_kernel, dim3((unsigned)h.n_jobs), dim3(512), 0, stream,
-                     (const WgradProblem*)problems_dev, qd, jobs, (float*)workspace);
+  if (ptops::option("PTOPS_WGRAD_OCC3"))      // A/B: three workgroups per CU = six waves per SIMD (<= 80 VGPRs; LDS 3 x 51.7 KB fits)
+    hipLaunchKernelGGL(gemm_split3_wgrad_grouped_kernel<6>, dim3((unsigned)h.n_jobs), dim3(512), 0, stream,
+                       (const WgradProblem*)problems_dev, qd, jobs, (float*)workspace);
+  else
+    hipLaunchKernelGGL(gemm_split3_wgrad_grouped_kernel<2>, dim3((unsigned)h.n_jobs), dim3(512), 0, stream,
+                       (const WgradProblem*)problems_dev, qd, jobs, (float*)workspace);
   int rc = ptops::check_launch("gemm_split3_wgrad_grouped_kernel");
   if (rc != PTOPS_OK) return rc;
   hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3((unsigned)h.n_rjobs), dim3(256), 0, stream,
