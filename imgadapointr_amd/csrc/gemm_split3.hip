@@ -502,10 +502,19 @@ struct WgradGroup {          // the tiles of one (problem, split): one XCD runs 
   long long cost;            // tiles x k-steps
 };
 
-int wgrad_group_target_steps(int steps_target) {
+// Job length in 16-row steps: explicit, or PTOPS_WGRAD_GROUP_STEPS, or chosen from the work: about 4096 jobs per launch
+// (eight per workgroup slot: enough to balance the XCD queues), never shorter than 288 steps (measured flat from 96 to
+// 384 at bs = 32) - so a 12-view batch (six times the rows) gets six times longer jobs instead of six
+// times the partial sums.
+int wgrad_group_target_steps(int steps_target, const int* mnk, int n) {
   if (steps_target > 0) return steps_target;
   const int opt = ptops::option("PTOPS_WGRAD_GROUP_STEPS");
-  return opt > 0 ? opt : 288;
+  if (opt > 0) return opt;
+  long long units = 0;                                   // tile x k-step units of the whole launch
+  for (int i = 0; i < n; ++i)
+    units += (long long)ptops::ceil_div(mnk[3 * i + 1], kBM) * ptops::ceil_div(mnk[3 * i + 2], kBN) * (mnk[3 * i] / kBK);
+  const long long t = units / 4096;
+  return (int)(t < 288 ? 288 : (t > 8192 ? 8192 : t));
 }
 
 // splits / steps per split of one problem for a target job length
@@ -525,7 +534,9 @@ void wgrad_group_split(int M, int target, int* splits, int* per) {
 PTOPS_API long long ptops_wgrad_group_plan(const int* mnk, const unsigned char* want_db, int n, int steps_target, void* plan,
                                            long long capacity) {
   if (!mnk || n <= 0) return 0;
-  const int target = wgrad_group_target_steps(steps_target);
+  for (int i = 0; i < n; ++i)
+    if (mnk[3 * i] < kBK || mnk[3 * i + 1] < 1 || mnk[3 * i + 2] < 1) return -1;
+  const int target = wgrad_group_target_steps(steps_target, mnk, n);
   std::vector<WgradPlanProblem> pp((size_t)n);
   std::vector<WgradGroup> groups;
   long long ws_floats = 0, n_rjobs = 0;
