@@ -41,6 +41,7 @@ struct GemmArgs {
   long long lda, ldb, ldc, ldg;
   int M, N, K;
   int tiles_n;
+  int debug_no_store;  // PTOPS_GEMM_DEBUG_NO_STORE=1: the epilogue writes nothing (timing experiments only)
 };
 
 struct Pieces {
@@ -173,6 +174,15 @@ __global__ __launch_bounds__(512, OCC) void gemm_split3_kernel(GemmArgs g) {
   }
 
   // epilogue: block j register r holds C[m0 + wr*32 + (r&3) + 8 (r>>2) + 4 half][n0 + wc*64 + j*32 + col]
+  if (g.debug_no_store) {                      // keep the accumulators alive without the 64 KB of stores
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[j][r];
+    if (s == 1.2345e-30f) g.C[0] = s;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wc * 64 + j * 32 + col;
@@ -424,6 +434,7 @@ static int gemm_split3_launch(const float* A, long long lda, int a_k_contiguous,
   g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldg = ldg;
   g.M = M, g.N = N, g.K = K;
   g.tiles_n = ptops::ceil_div(N, kBN);
+  g.debug_no_store = ptops::option("PTOPS_GEMM_DEBUG_NO_STORE");
   const long long blocks = (long long)ptops::ceil_div(M, kBM) * g.tiles_n;
   PTOPS_REQUIRE(blocks < (1LL << 31), "gemm_f32_split3: grid too large");
   dim3 grid((unsigned)blocks), block(512);
