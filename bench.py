@@ -282,6 +282,16 @@ class GemmProbe:
             out[name] = {"launches_per_step": n, "ms_per_step": round(ms, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 1)}
         if "gemm_split3_wgrad_grouped" in out:
             out["gemm_split3_wgrad_grouped"]["layers_per_launch"] = getattr(self, "grouped_problems", None)
+            pmc = os.path.join(ROOT, "profiles", "round3", "wgrad_grouped_pmc.json")   # separate rocprofv3 --pmc passes
+            if os.path.exists(pmc):
+                with open(pmc) as fh:
+                    k = json.load(fh)["kernels"][0]
+                d = k.get("derived", {})
+                out["gemm_split3_wgrad_grouped"]["pmc"] = {
+                    "source": "profiles/round3/wgrad_grouped_pmc.json", "launch_us": k.get("avg_duration_us_under_pmc"),
+                    "mfma_busy": d.get("mfma_busy_fraction"), "valu_busy": d.get("valu_busy_fraction"),
+                    "waves_per_simd": d.get("waves_resident_per_simd"), "clock_ghz": d.get("clock_ghz"),
+                    "traffic": d.get("hbm_traffic_bytes"), "fetch_bytes_raw": d.get("fetch_bytes_raw")}
         if tot_ms > 0:
             out.update({"ms_per_step": round(tot_ms, 3), "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                         "executed": round(6 * tot_fl / (tot_ms * 1e-3) / 1e12, 1),
