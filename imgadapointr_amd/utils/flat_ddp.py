@@ -37,10 +37,13 @@ from .. import _native
 
 
 class FlatDDP(nn.Module):
-    def __init__(self, module, bucket_mb=64, process_group=None, single_rank_collectives=False):
+    def __init__(self, module, bucket_mb=None, process_group=None, single_rank_collectives=False):
         """`single_rank_collectives`: issue the broadcasts / all-reduces even in a world of one rank (a way to run the
         exact RCCL call sequence on a one-GPU box, tests/test_runner_gpu.py); off, a single rank skips them."""
         super().__init__()
+        if bucket_mb is None:                     # PTOPS_DDP_BUCKET_MB: A/B of the bucket schedule (default 64)
+            import os
+            bucket_mb = float(os.environ.get("PTOPS_DDP_BUCKET_MB", "64"))
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -53,6 +56,8 @@ class FlatDDP(nn.Module):
         self._sync = True
         self._late = set()
         self._every_param = list(module.parameters())
+        self._learning, self._relearn = True, False
+        self._outside = None          # trainable parameters outside the buckets (name, parameter), cached by finalize()
         # RCCL averages inside the collective; gloo (CPU tests) only sums, so divide afterwards there
         self._avg_in_collective = (self._collective and dist.get_backend(process_group) == "nccl")
         # identical start: rank 0's parameters and buffers everywhere (as DDP does at wrap time)
@@ -92,13 +97,19 @@ class FlatDDP(nn.Module):
         for plist in buckets:
             n = sum(p.numel() for p in plist)
             flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
-            b = dict(flat=flat, params=plist, pending=len(plist), handle=None, views=[], packed=False)
+            b = dict(flat=flat, params=plist, pending=len(plist), handle=None, views=[], packed=False, last=None)
             off = 0
             for p in plist:
                 b["views"].append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
                 self._param_bucket[p] = b
             self._buckets.append(b)
+        # Hooks: the first averaged backward after this runs one hook per parameter and LEARNS which parameter completes
+        # each bucket (a static graph hands its gradients over in the same order every step); from then on only those
+        # parameters carry a hook (5 Python callbacks per backward instead of 330: the autograd thread enqueues the end
+        # of backward noticeably faster).  The slim hook checks that its bucket really is complete; if the order ever
+        # changes the bucket is finished by finalize() without overlap and the order is learned again.
+        self._learning = True
         for p in self._param_bucket:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -126,6 +137,7 @@ class FlatDDP(nn.Module):
             b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.process_group, async_op=async_op)
 
     def _on_grad(self, p):
+        """Learning mode: one call per parameter and backward."""
         if not self._sync:
             return
         b = self._param_bucket.get(p)
@@ -133,7 +145,32 @@ class FlatDDP(nn.Module):
             return
         b["pending"] -= 1
         if b["pending"] == 0:
+            b["last"] = p
             self._launch(b)
+
+    def _on_last(self, p):
+        """Slim mode: called for the parameter that completed its bucket when the order was learned."""
+        if not self._sync:
+            return
+        b = self._param_bucket.get(p)
+        if b is None or b["packed"]:
+            return
+        if all(q.grad is not None for q in b["params"]):
+            self._launch(b)
+        else:                                   # the order changed: finalize() completes this bucket; learn again
+            self._relearn = True
+
+    def _set_hooks(self, slim):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if slim:
+            for b in self._buckets:
+                self._hooks.append(b["last"].register_post_accumulate_grad_hook(self._on_last))
+        else:
+            for p in self._param_bucket:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._learning = not slim
 
     # ------------------------------------------------------------------------- step protocol
     def zero_grad(self, set_to_none=True):
@@ -170,6 +207,14 @@ class FlatDDP(nn.Module):
         for b in self._buckets:
             if not b["packed"]:          # some hook did not fire, or averaging was off during backward
                 self._launch(b)
+        if self._sync and self._buckets:
+            if self._learning and all(b["last"] is not None for b in self._buckets):
+                self._set_hooks(slim=True)                  # the order is known: one hook per bucket from now on
+            elif not self._learning and self._relearn:
+                for b in self._buckets:
+                    b["last"] = None
+                self._set_hooks(slim=False)
+            self._relearn = False
         if self._collective:
             for b in self._buckets:
                 if b["handle"] is not None:
@@ -179,8 +224,11 @@ class FlatDDP(nn.Module):
             # A parameter outside the buckets that suddenly received a gradient: no collective here (other ranks may
             # not have it and would never enter one).  Dropping the local gradient keeps the parameter identical on
             # every rank; check_late_gradients() reports it on all of them.
-            for n, p in self.module.named_parameters():
-                if p.requires_grad and p.grad is not None and p not in self._param_bucket:
+            if self._outside is None:       # cached: walking the module tree costs 0.2 ms of host time per step
+                self._outside = [(n, p) for n, p in self.module.named_parameters()
+                                 if p.requires_grad and p not in self._param_bucket]
+            for n, p in self._outside:
+                if p.grad is not None:
                     p.grad = None
                     self._late.add(n)
 
@@ -204,6 +252,8 @@ class FlatDDP(nn.Module):
             h.remove()
         self._hooks = []
         self._buckets, self._param_bucket = None, {}
+        self._outside = None
+        self._learning, self._relearn = True, False
         self._discovered = False
         self._late = set()
         self.zero_grad()

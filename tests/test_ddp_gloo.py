@@ -230,3 +230,54 @@ def _consistency_worker(rank, world, port, out):
 @pytest.mark.timeout(300)
 def test_flat_ddp_rank_consistency(tmp_path):
     mp.spawn(_consistency_worker, args=(2, 29614, str(tmp_path / "x")), nprocs=2, join=True)
+
+
+def test_flat_ddp_learns_which_parameter_completes_a_bucket():
+    """After one averaged backward with a hook per parameter FlatDDP keeps ONE hook per bucket (on the parameter whose
+    gradient arrived last); the slim hook launches the bucket during backward as before, and a backward in which that
+    parameter's bucket is NOT complete when it fires (the graph changed) is finished by finalize() and makes the order
+    be learned again.  Single process, no process group: the bookkeeping is the same on every world size."""
+    sys.path.insert(0, ROOT)
+    from imgadapointr_amd.utils.flat_ddp import FlatDDP
+    torch.manual_seed(3)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.f = nn.ModuleList([nn.Linear(6, 6) for _ in range(6)])
+
+        def forward(self, x, reverse=False):
+            order = list(self.f)[::-1] if reverse else list(self.f)
+            for m in order:
+                x = torch.tanh(m(x))
+            return x
+
+    net, ref = Net(), Net()
+    ref.load_state_dict(net.state_dict())
+    ddp = FlatDDP(net, bucket_mb=0.0003)          # ~2 layers per bucket
+    x = torch.randn(5, 6)
+
+    def step(reverse=False):
+        ddp.zero_grad()
+        ref.zero_grad(set_to_none=True)
+        ddp(x, reverse).square().sum().backward()
+        launched_in_backward = [b["packed"] for b in (ddp._buckets or [])]
+        ddp.finalize()
+        ref(x, reverse).square().sum().backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad)
+        return launched_in_backward
+
+    step()                                        # discovery: buckets are built in finalize()
+    n_params, n_buckets = len(list(net.parameters())), len(ddp._buckets)
+    assert n_buckets >= 3 and len(ddp._hooks) == n_params and ddp._learning
+    assert all(step())                            # learning step: every bucket launched from a hook
+    assert len(ddp._hooks) == n_buckets and not ddp._learning
+    for _ in range(2):
+        assert all(step())                        # slim hooks: still launched during backward
+    # reversed layer order: gradients arrive in another order, some slim hook fires on an incomplete bucket
+    launched = step(reverse=True)
+    assert not all(launched)                      # ... finalize() had to finish those buckets (values checked in step())
+    assert len(ddp._hooks) == n_params and ddp._learning           # and the order is being learned again
+    assert all(step(reverse=True))
+    assert len(ddp._hooks) == n_buckets
