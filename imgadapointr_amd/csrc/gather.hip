@@ -522,7 +522,9 @@ PTOPS_API int ptops_gather_max_act_backward(const float* grad_out, const float* 
                                             int N, int C, int S, float* grad_p, float* grad_add, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PTOPS_REQUIRE(B >= 0 && N >= 1 && C >= 1 && S >= 0, "gather_max_act_backward: bad size");
-  PTOPS_REQUIRE(N <= 1024 && B <= 65535, "gather_max_act_backward: at most 1024 source rows and 65535 clouds (N=%d B=%d)", N, B);
+  // S <= 65536: the fixed-point sums hold 2^16 addends of up to 2^47 in 63 bits (a source row can be the arg-max of every query)
+  PTOPS_REQUIRE(N <= 1024 && B <= 65535 && S <= 65536,
+                "gather_max_act_backward: at most 1024 source rows, 65535 clouds, 65536 queries (N=%d B=%d S=%d)", N, B, S);
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_p, "gather_max_act_backward: null pointer");
   if ((long long)B * S * C == 0) {
@@ -531,8 +533,10 @@ PTOPS_API int ptops_gather_max_act_backward(const float* grad_out, const float* 
   }
   PTOPS_REQUIRE(grad_out && out && arg && grad_add, "gather_max_act_backward: null pointer");
   const size_t lds = sizeof(unsigned long long) * (size_t)kGmCT * (N + 1);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kGmCT * 1025));
+  PTOPS_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(unsigned long long) * kGmCT * 1025)) == hipSuccess,
+                "gather_max_act_backward: the device refused %zu bytes of dynamic LDS", sizeof(unsigned long long) * kGmCT * 1025);
   hipLaunchKernelGGL(gather_max_bwd_lds_kernel<true>, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out, arg,
                      N, C, S, grad_p, out, slope, grad_add);
   return ptops::check_launch("gather_max_bwd_lds_kernel");
@@ -545,11 +549,14 @@ PTOPS_API int ptops_gather_max_backward(const float* grad_out, const int32_t* ar
   if (B == 0) return PTOPS_OK;
   PTOPS_REQUIRE(grad_p, "gather_max_backward: null pointer");
   const long long total = (long long)B * S * C;
-  if (total > 0 && N <= 1024 && B <= 65535) {
+  // the fixed-point tile needs N <= 1024 (LDS) and S <= 65536 (2^16 addends of up to 2^47 fit 63 bits); anything else, or a
+  // device that refuses the 131 KB of dynamic LDS, takes the atomic kernel below
+  if (total > 0 && N <= 1024 && B <= 65535 && S <= 65536 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(sizeof(unsigned long long) * kGmCT * 1025)) == hipSuccess) {
     PTOPS_REQUIRE(grad_out && arg, "gather_max_backward: null pointer");
     const size_t lds = sizeof(unsigned long long) * (size_t)kGmCT * (N + 1);   // <= 131 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_max_bwd_lds_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kGmCT * 1025));
     hipLaunchKernelGGL(gather_max_bwd_lds_kernel<false>, dim3(ptops::ceil_div(C, kGmCT), B), dim3(kTPB), lds, stream, grad_out,
                        arg, N, C, S, grad_p, (const float*)nullptr, 0.f, (float*)nullptr);
     return ptops::check_launch("gather_max_bwd_lds_kernel");

@@ -34,7 +34,18 @@ USE_MFMA_ATTENTION = True
 # 128 tokens up: 352 / 176 / 117 us at the bs = 32 decoder-self / cross / encoder shapes);
 # "fused": the single-pass f32-MFMA backward (5 GEMMs; 430 / 206 / 114 us);
 # False: PyTorch-ROCm's aten::_efficient_attention_backward, which consumes the same (out, logsumexp) pair
-USE_MFMA_ATTENTION_BWD = os.environ.get("PTOPS_ATTN_BWD", "split")       # A/B switch: split | fused
+def _parse_attn_bwd(value):
+    """PTOPS_ATTN_BWD -> "split" | "fused" | False; anything else is an error (a typo must not pick a kernel silently, and
+    '0' / 'false' must mean the aten backward, not "truthy string")."""
+    v = str(value).strip().lower()
+    if v in ("split", "fused"):
+        return v
+    if v in ("0", "false", "off", "aten", "none", ""):
+        return False
+    raise ValueError(f"PTOPS_ATTN_BWD={value!r}: expected split, fused or 0")
+
+
+USE_MFMA_ATTENTION_BWD = _parse_attn_bwd(os.environ.get("PTOPS_ATTN_BWD", "split"))       # A/B switch
 _LN2 = 0.6931471805599453
 _bias_cache = {}
 _zero_cache = {}

@@ -17,6 +17,31 @@ from ..utils.logger import print_log
 from ..utils.misc import build_lambda_bnsche, build_lambda_sche, worker_init_fn
 
 
+REFERENCE_DISTRIBUTED_BS = 64      # what the reference's distributed loader uses whatever the YAML says (builder.py:19)
+
+
+def resolve_batch_size(total_bs, world_size, distributed, override=None, logger=None):
+    """Per-rank training batch from a YAML's `total_bs` (main.py:43-47 of the reference: total_bs // world_size).
+
+    The reference's distributed loader ignores the result and hard-codes 64 per rank (builder.py:19); several of its
+    YAMLs therefore carry a placeholder (`total_bs: 1` in cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml),
+    which the YAML drop-in contract keeps.  This build honours the YAML, so the placeholder case needs a defined meaning:
+    `override` (`--total_bs N` on the command line) wins; otherwise, in distributed mode, a `total_bs` smaller than the
+    number of ranks - not a batch any launch could split - falls back to the reference's effective 64 per rank with a
+    warning.  Anything else that does not divide evenly is an error, as in the reference."""
+    if override is not None:
+        total_bs = int(override)
+    if not distributed:
+        return int(total_bs)
+    if override is None and total_bs < world_size:
+        print_log(f'[WARNING] total_bs = {total_bs} < world_size = {world_size}: using the reference\'s distributed '
+                  f'batch of {REFERENCE_DISTRIBUTED_BS} per rank (its loader hard-codes it); pass --total_bs to choose',
+                  logger=logger)
+        return REFERENCE_DISTRIBUTED_BS
+    assert total_bs % world_size == 0, f'total_bs {total_bs} is not divisible by world_size {world_size}'
+    return int(total_bs) // world_size
+
+
 def dataset_builder(args, config):
     dataset = build_dataset_from_cfg(config._base_, config.others)
     shuffle = config.others.subset == 'train'

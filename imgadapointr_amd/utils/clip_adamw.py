@@ -76,10 +76,16 @@ class ClipAdamW(torch.optim.AdamW):
         n = len(params)
         chunk = int(_native.load().ptops_adamw_chunk_elements())
         assert int(_native.load().ptops_adamw_row_bytes()) == _ROW
+        group = {id(p): g for g in self.param_groups for p in g["params"]}
         for p in params:
             st = self.state[p]
             if len(st) == 0:
-                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                # where torch's own `_init_group` puts it: the fused / capturable multi-tensor AdamW reads `step` through a
+                # device pointer, so a later stock `step()` (external caller, unsupported parameter set) must find it there
+                g = group[id(p)]
+                on_device = bool(g.get("fused") or g.get("capturable"))
+                st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device) if on_device
+                              else torch.tensor(0.0, dtype=torch.float32))
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         rows = np.zeros((n, _ROW // 8), dtype=np.uint64)                 # 8 x 8 bytes per row
@@ -99,7 +105,8 @@ class ClipAdamW(torch.optim.AdamW):
             "key": tuple(id(p) for p in params), "params": params, "group_of": np.asarray(group_of), "rows": rows,
             # step counts live here between checkpoints (335 CPU-tensor increments per step cost a millisecond of host
             # time); `_sync_steps` writes them back into state[p]["step"] whenever somebody else may look
-            "steps": np.array([float(self.state[p]["step"]) for p in params], dtype=np.float64),
+            "steps": torch.stack([self.state[p]["step"].detach().reshape(()).to("cpu", torch.float64)
+                                  for p in params]).numpy().copy(),
             "n_chunks": len(tensor_of),
             "chunks_dev": torch.from_numpy(chunks.view(np.uint8).reshape(-1)).to(dev),
             "rows_dev": torch.empty(n * _ROW, dtype=torch.uint8, device=dev),

@@ -57,6 +57,7 @@ class FlatDDP(nn.Module):
         self._late = set()
         self._every_param = list(module.parameters())
         self._learning, self._relearn = True, False
+        self._allow_slim = True
         self._outside = None          # trainable parameters outside the buckets (name, parameter), cached by finalize()
         # RCCL averages inside the collective; gloo (CPU tests) only sums, so divide afterwards there
         self._avg_in_collective = (self._collective and dist.get_backend(process_group) == "nccl")
@@ -69,7 +70,18 @@ class FlatDDP(nn.Module):
         return self.module(*args, **kwargs)
 
     def set_sync(self, sync):
+        """Called before every backward: `sync` False for all but the last micro-batch of an accumulated update.
+
+        Gradient accumulation (any backward that is not averaged) rules out the one-hook-per-bucket mode for good: there
+        every `.grad` is non-None from the first micro-batch on, so the slim hook's completeness check would pass before
+        the bucket's remaining gradients of THIS backward have accumulated; the per-parameter counting hooks stay."""
         self._sync = bool(sync)
+        if not self._sync and self._allow_slim:
+            self._allow_slim = False
+            if self._buckets and not self._learning:
+                for b in self._buckets:
+                    b["last"] = None
+                self._set_hooks(slim=False)
 
     # ------------------------------------------------------------------ bucket construction
     def _build_buckets(self, used_params):
@@ -208,7 +220,7 @@ class FlatDDP(nn.Module):
             if not b["packed"]:          # some hook did not fire, or averaging was off during backward
                 self._launch(b)
         if self._sync and self._buckets:
-            if self._learning and all(b["last"] is not None for b in self._buckets):
+            if self._learning and self._allow_slim and all(b["last"] is not None for b in self._buckets):
                 self._set_hooks(slim=True)                  # the order is known: one hook per bucket from now on
             elif not self._learning and self._relearn:
                 for b in self._buckets:

@@ -10,6 +10,7 @@ import time
 
 import torch
 
+from imgadapointr_amd.tools import builder
 from imgadapointr_amd.tools.runner import run_net, test_net
 from imgadapointr_amd.utils import dist_utils, misc, parser
 from imgadapointr_amd.utils.config import get_config, log_args_to_file, log_config_to_file
@@ -58,11 +59,8 @@ def main():
         train_writer = _writer(os.path.join(args.tfboard_path, 'train'))
         val_writer = _writer(os.path.join(args.tfboard_path, 'test'))
     config = get_config(args, logger=logger)
-    if args.distributed:
-        assert config.total_bs % args.world_size == 0
-        config.dataset.train.others.bs = config.total_bs // args.world_size
-    else:
-        config.dataset.train.others.bs = config.total_bs
+    config.dataset.train.others.bs = builder.resolve_batch_size(
+        config.total_bs, args.world_size, args.distributed, getattr(args, 'total_bs', None), logger=logger)
     log_args_to_file(args, 'args', logger=logger)
     log_config_to_file(config, 'config', logger=logger)
     logger.info(f'Distributed training: {args.distributed}')

@@ -484,13 +484,27 @@ class _FixedDropout(torch.nn.Module):
         return x * self.keep * (1.0 / (1.0 - self.p)) if self.training else x
 
 
-def check_trainstep(case, device):
-    """ONE full `TrainStep` (forward, get_loss, backward, clip + AdamW — the production step object of
-    tools/runner.py, fast paths as shipped) of a fused model family at B = 2 against the reference fixture
-    tests/golden/trainstep_<case>.npz: train outputs, both losses (CD-L1 x1000 within the north_star's 1e-3), the set
-    of parameters without gradient, total and sampled gradient norms, whole gradient vectors, parameters after the
-    update, and the frozen segmentator's running statistics (its BatchNorms stay in train mode, runner.py:115)."""
-    import json
+class _Pinned:
+    """Library choices that are free to differ from run to run, pinned for the length of a parity run: MIOpen's
+    per-process search (`benchmark`) off and its deterministic algorithms on."""
+
+    def __enter__(self):
+        b = torch.backends.cudnn
+        self.saved = (b.deterministic, b.benchmark)
+        b.deterministic, b.benchmark = True, False
+        return self
+
+    def __exit__(self, *exc):
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = self.saved
+
+
+def prepare_trainstep(case, device, replay_scores=True):
+    """Model, production `TrainStep`, inputs and fixture of a train-step case with every recorded RNG consumer and chaotic
+    decision of the reference's forward replayed: the denoise jitter (passed as `denoise_noise`), the two Dropout(0.4)
+    keep-masks of the train-mode GDANet (GDANet_ptseg.py:59-61) and — round 4 — the query-ranking scores
+    (AdaPoinTr.py:119-121: the 512-of-768 selection; two scores closer than rounding swap places between implementations).
+    The scores are replayed by a forward hook on the `query_ranking` module, whose parameters receive no gradient in
+    either implementation (argsort is not differentiable), so nothing on the product side knows about it."""
     from golden_util import trainstep_inputs
     from imgadapointr_amd.tools import builder
     from imgadapointr_amd.tools.runner import TrainStep
@@ -499,9 +513,6 @@ def check_trainstep(case, device):
         mt = json.load(fh)
     model, cfg, spec = build_trainstep_model(case, device)
     model.train()
-    named = dict(model.named_parameters())
-    assert sum(1 for p in named.values() if p.requires_grad) == mt["n_trainable"]
-    before = {n[len("after/"):]: named[n[len("after/"):]].detach().clone() for n in g.files if n.startswith("after/")}
     step = TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
     partial, gt, img, cls = trainstep_inputs(case)
     extra = []
@@ -511,52 +522,116 @@ def check_trainstep(case, device):
         extra.append(None)
     if cls is not None:
         extra.append(t(cls, device))
-    # replay the reference's Dropout(0.4) masks of the (train-mode, frozen) GDANet, GDANet_ptseg.py:59-61
     for i, name in enumerate(("dp1", "dp2")):
         if f"dropout_mask_{i}" in g.files:
             shape = tuple(int(x) for x in g[f"dropout_mask_{i}_shape"])
             mask = np.unpackbits(g[f"dropout_mask_{i}"])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
             setattr(model.base_model.segmentator, name, _FixedDropout(t(mask, device), 0.4))
-    grads, outs = {}, []
+    if replay_scores:
+        scores = t(g["query_scores"], device).unsqueeze(-1)
+        model.base_model.query_ranking.register_forward_hook(lambda m, a, o: scores.to(o.dtype))
+
+    def run():
+        return step(t(partial, device), t(gt, device), tuple(extra), epoch=spec["epoch"],
+                    denoise_noise=t(g["train_noise"], device))
+    return model, cfg, spec, step, run, g, mt
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def check_trainstep(case, device):
+    """ONE full `TrainStep` (forward, get_loss, backward, clip + AdamW — the production step object of
+    tools/runner.py, fast paths as shipped) of a fused model family at B = 2 against the reference fixture
+    tests/golden/trainstep_<case>.npz: train outputs, both losses (CD-L1 x1000 within the north_star's 1e-3), the set
+    of parameters without gradient, total and per-tensor gradient norms, whole gradient vectors, parameters after the
+    update, and the frozen segmentator's running statistics (its BatchNorms stay in train mode, runner.py:115).
+
+    EVERY deviation is collected and reported in one assertion, together with what localises it: the outputs of the two
+    library-backed branches (ResNet18 / GDANet: MIOpen convolutions on the GPU) against the reference's, and the tensors
+    whose |g|^2 moved most — round 3's one failing run (total |g|^2 2.1 % low, everything else in bounds) could not say
+    what had moved."""
+    with _Pinned():
+        return _check_trainstep(case, device)
+
+
+def _check_trainstep(case, device):
+    model, cfg, spec, step, run, g, mt = prepare_trainstep(case, device)
+    named = dict(model.named_parameters())
+    assert sum(1 for p in named.values() if p.requires_grad) == mt["n_trainable"]
+    before = {n[len("after/"):]: named[n[len("after/"):]].detach().clone() for n in g.files if n.startswith("after/")}
+    grads, outs, branch = {}, [], {}
     step.before_update = lambda: grads.update({n: p.grad.detach().clone() for n, p in named.items() if p.grad is not None})
-    hook = model.register_forward_hook(lambda m, a, o: outs.append(o))
-    l_den, l_rec = step(t(partial, device), t(gt, device), tuple(extra), epoch=spec["epoch"],
-                        denoise_noise=t(g["train_noise"], device))
-    hook.remove()
+    hooks = [model.register_forward_hook(lambda m, a, o: outs.append(o))]
+    if hasattr(model.base_model, "im_encoder"):
+        hooks.append(model.base_model.im_encoder.register_forward_hook(
+            lambda m, a, o: branch.__setitem__("img", o.detach())))
+    if hasattr(model.base_model, "segmentator"):
+        hooks.append(model.base_model.segmentator.register_forward_hook(
+            lambda m, a, o: branch.__setitem__("seg", o[0].detach())))
+    l_den, l_rec = run()
+    for h in hooks:
+        h.remove()
     ret = outs[0]
+    B = ret[0].shape[0]
+    problems, report = [], {}
+
+    def check(name, value, limit):
+        report[name] = value
+        if not value < limit:
+            problems.append(f"{name} = {value:.3e} (limit {limit:.1e})")
+
+    # the library-backed branches first: they are upstream of everything below
+    if "img" in branch:
+        check("img_tokens_rel", _rel(branch["img"].reshape(B, -1)[:, :4096].cpu().numpy(), g["img_tokens_head"]), 1e-4)
+        check("img_tokens_sq_norm_rel", abs(float((branch["img"].double() ** 2).sum()) / float(g["img_tokens_sq_norm"]) - 1), 1e-4)
+    if "seg" in branch:
+        # GDANet in train mode over B = 2 (batch statistics, feature-space top-k): compared for the record, bounded loosely
+        check("seg_emb_rel", _rel(branch["seg"].reshape(B, -1)[:, :4096].cpu().numpy(), g["seg_emb_head"]), 5e-2)
     tol = 3e-4
-    d_out = (maxdiff(ret[1].detach().cpu().numpy(), g["denoised_coarse"]),
-             maxdiff(ret[2][:, :512].detach().cpu().numpy(), g["denoised_fine_head"]))
-    assert max(d_out) < tol, d_out
-    compare_ranked(ret[0].detach().cpu().numpy(), ret[3][:, :2048].detach().cpu().numpy(), g["pred_coarse"],
-                   g["pred_fine_head"], tol)
-    d_loss = (abs(l_den.item() - float(g["loss_denoised"])) * 1000, abs(l_rec.item() - float(g["loss_recon"])) * 1000)
-    # losses x 1000 (the logged unit).  The seg case's frozen GDANet runs on MIOpen / rocBLAS kernels the library picks at
-    # run time: its forward differs at rounding level from box to box (1.3e-3 seen), on top of the conditioning measured by
-    # benchmarks/trainstep_spread.py
-    assert max(d_loss) < (4e-3 if case == "seg" else 1e-3), d_loss
+    check("out_denoised_coarse", maxdiff(ret[1].detach().cpu().numpy(), g["denoised_coarse"]), tol)
+    check("out_denoised_fine", maxdiff(ret[2][:, :512].detach().cpu().numpy(), g["denoised_fine_head"]), tol)
+    # with the scores replayed the queries keep the reference's order: rows are compared in place
+    check("out_pred_coarse", maxdiff(ret[0].detach().cpu().numpy(), g["pred_coarse"]), tol)
+    check("out_pred_fine", maxdiff(ret[3][:, :2048].detach().cpu().numpy(), g["pred_fine_head"]), tol)
+    # losses x 1000 (the logged unit): the north_star's 1e-3 for every case
+    check("loss_denoised_x1000", abs(l_den.item() - float(g["loss_denoised"])) * 1000, 1e-3)
+    check("loss_recon_x1000", abs(l_rec.item() - float(g["loss_recon"])) * 1000, 1e-3)
     no_grad = sorted(n for n, p in named.items() if p.requires_grad and n not in grads)
-    assert no_grad == mt["no_grad_params"], (no_grad, mt["no_grad_params"])
-    assert not any(n in grads for n, p in named.items() if not p.requires_grad)
+    if no_grad != mt["no_grad_params"]:
+        problems.append(f"parameters without gradient: {sorted(set(no_grad) ^ set(mt['no_grad_params']))}")
+    if any(n in grads for n, p in named.items() if not p.requires_grad):
+        problems.append("a frozen parameter received a gradient")
     gsq = {n: float((v.double() ** 2).sum()) for n, v in grads.items()}
     total, want_total = sum(gsq.values()), float(g["grad_sq_norm_total"])
     # Resolution of the gradient comparison = what rounding alone does to this fixture, measured by running the step
     # with the GEMM / attention / edge-conv kernels exchanged for the library's and the literal forms
-    # (benchmarks/trainstep_spread.py -> profiles/round3/trainstep_spread_v1.log).  img / segenc: arms agree to 4e-3 in
-    # the gradient vector and 1.4e-3 in |g|^2 - the AdaPoinTr resolution (arg-max flips at near-ties).  seg: the arms
-    # differ from EACH OTHER by 2-5 % in the vector and 0.5 % in |g|^2 (GDANet in train mode over B = 2: feature-space
-    # top-k, top-M sharp/gentle selection and a hard distance mask after the predicted coarse cloud), so that is all this
-    # fixture can resolve; outputs and losses above stay at 3e-4 / 1e-3.
-    # On the GPU the image / segmentation branches run on MIOpen, which picks its convolution algorithms per process: on
-    # one box in six the img step came out with |g|^2 2.1 % low (3.1255 vs 3.1926; outputs and losses still at 3e-4 /
-    # 1e-3: an arg-max flip re-routes gradient without changing a forward value) while three repeats on the next box
-    # agreed to 7e-5 (profiles/round3/trainstep_spread_img_v1.log).  So every case with such a branch gets the resolution
-    # of the worst-conditioned one there; the CPU run is deterministic and keeps the tight bound.
-    loose = case == "seg" or (str(device) != "cpu" and case in ("img", "segenc"))
+    # (benchmarks/trainstep_spread.py -> profiles/round3/trainstep_spread_v1.log) and, round 4, with the branch outputs
+    # perturbed on the CPU (benchmarks/trainstep_sensitivity.py -> profiles/round4/trainstep_sensitivity_v1.log).
+    # img / segenc: arms agree to 4e-3 in the gradient vector and 1.4e-3 in |g|^2 - the AdaPoinTr resolution (arg-max
+    # flips at near-ties); relative perturbations of the image tokens from 1e-6 to 1e-3 all move |g|^2 by <= 1e-3, and it
+    # takes 1e-2 (bf16-level precision) to move it by the 2 % of round 3's failing run - which is why the image tokens are
+    # compared first.  seg: the arms differ from EACH OTHER by 2-5 % in the vector and 0.5 % in |g|^2 (GDANet in train
+    # mode over B = 2: feature-space top-k, top-M sharp/gentle selection and a hard distance mask after the predicted
+    # coarse cloud; an fp32-ulp perturbation of the cloud handed to GDANet moves |g|^2 by 2.4e-3), so that is all this
+    # fixture can resolve; outputs and losses stay at 3e-4 / 1e-3 for every case on every device.
+    loose = case == "seg"
     tol_total, tol_vec = (3e-2, 8e-2) if loose else (5e-3, 3e-2)
-    assert abs(total - want_total) <= tol_total * want_total, (total, want_total)
+    check("grad_sq_total_rel", abs(total - want_total) / want_total, tol_total)
+    want_all = mt["grad_sq_norm_all"]
+    # per tensor: deviation of |g_n|^2 as a share of its own size (tensors above 1e-9 of the total) ...
+    dev = {n: abs(gsq.get(n, 0.0) - v) / v for n, v in want_all.items() if v > 1e-9 * want_total}
+    worst = sorted(dev, key=dev.get, reverse=True)[:6]
+    report["grad_sq_worst_tensors"] = {n: (gsq.get(n, 0.0), want_all[n]) for n in worst}
+    check("grad_sq_per_tensor_rel", dev[worst[0]], 5 * tol_vec)
+    # ... and as a share of the total: which tensors carry a deviation of the total
+    share = {n: (gsq.get(n, 0.0) - v) / want_total for n, v in want_all.items()}
+    carriers = sorted(share, key=lambda n: abs(share[n]), reverse=True)[:6]
+    report["grad_sq_total_carriers"] = {n: share[n] for n in carriers}
     d_norm = max(abs(gsq[n] - v) / max(v, 1e-12) for n, v in mt["grad_sq_norm_sample"].items() if v > 1e-9 * want_total)
-    assert d_norm < tol_vec, d_norm
+    check("grad_sq_sample_rel", d_norm, tol_vec)
     d_vec = {}
     for key in g.files:
         if key.startswith("grad/"):
@@ -566,11 +641,14 @@ def check_trainstep(case, device):
             if np.linalg.norm(want) < 1e-4 * np.sqrt(want_total):
                 # e.g. a k_map bias: softmax is invariant to a constant added to every key's logit, so this gradient is
                 # zero in exact arithmetic and pure rounding noise in both implementations; only its size is checked
-                assert np.linalg.norm(got) < 1e-3 * np.sqrt(want_total), n
+                check("grad_null/" + n, float(np.linalg.norm(got)), 1e-3 * np.sqrt(want_total))
                 continue
             d_vec[n] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
-    assert len(d_vec) >= 12 and max(d_vec.values()) < tol_vec, d_vec
-    assert abs(float(np.sqrt(total)) - float(g["grad_norm_before_clip"])) < tol_total * float(g["grad_norm_before_clip"])
+    assert len(d_vec) >= 12
+    worst_vec = max(d_vec, key=d_vec.get)
+    report["grad_vec_worst"] = worst_vec
+    check("grad_vec_rel", d_vec[worst_vec], tol_vec)
+    check("grad_norm_before_clip_rel", abs(float(np.sqrt(total)) / float(g["grad_norm_before_clip"]) - 1), tol_total)
     # after the update: AdamW's first step moves every element by ~lr * sign(g) (lr 1e-4), so an element whose gradient
     # is at rounding level may land 2e-4 away; everything else must agree to a small fraction of one step
     lr = float(cfg.optimizer.kwargs.lr)
@@ -580,25 +658,68 @@ def check_trainstep(case, device):
         got = named[n].detach().reshape(-1)[:4096].cpu().numpy()
         was = b.reshape(-1)[:4096].cpu().numpy()
         if np.abs(want - was).max() < 0.2 * lr:       # a k_map bias again: gradient at rounding level, below Adam's eps
-            assert np.abs(got - was).max() < 1.1 * lr, n
+            check("after_null/" + n, float(np.abs(got - was).max()), 1.1 * lr)
             continue
         diff = np.abs(got - want)
         far += int((diff > 0.05 * lr).sum())
         n_el += diff.size
-        assert diff.max() <= 2.2 * lr, (n, diff.max())
+        check("after_max/" + n, float(diff.max()), 2.2 * lr + 1e-12)
         moved = max(moved, float(np.abs(got - was).max()))
     # a gradient vector that agrees to 1-2 % (arg-max flips, above) has about that share of elements near zero whose
     # sign, and with it the whole first step, may differ
-    assert far <= (0.12 if loose else 0.06) * n_el, (far, n_el)
-    assert 0.5 * lr < moved < 1.5 * lr, moved
-    d_rm = None
+    check("after_far_frac", far / n_el, 0.12 if loose else 0.06)
+    check("after_step_size_low", 0.5 * lr - moved, 0.0)
+    check("after_step_size_high", moved - 1.5 * lr, 0.0)
     if "seg_first_running_mean" in g.files:
         bn = next(m for m in model.base_model.segmentator.modules() if isinstance(m, torch.nn.BatchNorm2d))
-        d_rm = maxdiff(bn.running_mean.cpu().numpy(), g["seg_first_running_mean"])
-        assert d_rm < 1e-5, d_rm
-        assert all(p.grad is None for p in model.base_model.segmentator.parameters())
-    return dict(out=d_out, loss_x1000=d_loss, grad_total_rel=abs(total - want_total) / want_total, grad_sample_rel=d_norm,
-                grad_vec_rel=max(d_vec.values()), after_far_frac=far / n_el, seg_running_mean=d_rm)
+        check("seg_running_mean", maxdiff(bn.running_mean.cpu().numpy(), g["seg_first_running_mean"]), 1e-5)
+        if not all(p.grad is None for p in model.base_model.segmentator.parameters()):
+            problems.append("the frozen segmentator holds a gradient")
+    assert not problems, "train step %s on %s deviates from the reference fixture:\n  %s\nfull report: %s" % (
+        case, device, "\n  ".join(problems), json.dumps(report, indent=1, sort_keys=True, default=str))
+    return report
+
+
+def check_trainstep_reproducible(case, device):
+    """The same `TrainStep` of a fused family twice in ONE process from the same weights: every gradient outside the
+    library-backed branches (ResNet18 / GDANet run on MIOpen, whose kernels this build does not own) must come out
+    bit-identical - the padded-head `multihead_attention`, add + LayerNorm and fusion layers run on libptops kernels, and a
+    race there would show here, not as "MIOpen picked another kernel".  Returns (number of tensors compared, the names of
+    library-branch tensors that differ between the runs - informational)."""
+    with _Pinned():
+        got, first = [], {}
+        for r in range(2):
+            torch.manual_seed(0)
+            model, cfg, spec, step, run, g, mt = prepare_trainstep(case, device)
+            grads, same = {}, {}
+
+            def pin(key):
+                # run 2 continues from run 1's branch output (written into the output in place, so the branch's own
+                # backward is untouched): what follows the branch then sees identical bits whatever MIOpen did
+                def hook(m, a, o):
+                    out = o[0] if isinstance(o, tuple) else o
+                    if r == 0:
+                        first[key] = out.detach().clone()
+                    else:
+                        same[key] = bool(torch.equal(out.detach(), first[key]))
+                        out.data.copy_(first[key])
+                return hook
+            for key in ("im_encoder", "segmentator"):
+                if hasattr(model.base_model, key):
+                    getattr(model.base_model, key).register_forward_hook(pin(key))
+            step.before_update = lambda: grads.update(
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            losses = run()
+            got.append((grads, [x.item() for x in losses], same))
+            del model, step
+    (g1, l1, _), (g2, l2, branch_same) = got
+    assert g1.keys() == g2.keys()
+    lib = lambda n: ".im_encoder." in n or ".segmentator." in n        # noqa: E731
+    differ = sorted(n for n in g1 if not torch.equal(g1[n], g2[n]))
+    ours = [n for n in differ if not lib(n)]
+    assert l1 == l2 and not ours, (l1, l2, "branch outputs bit-identical between the runs: %s" % branch_same,
+                                   {n: float((g1[n] - g2[n]).abs().max() / g1[n].abs().max()) for n in ours[:8]})
+    return sum(1 for n in g1 if not lib(n)), [n for n in differ if lib(n)]
 
 
 def check_multi_view(device, views=3):

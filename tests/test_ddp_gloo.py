@@ -281,3 +281,50 @@ def test_flat_ddp_learns_which_parameter_completes_a_bucket():
     assert len(ddp._hooks) == n_params and ddp._learning           # and the order is being learned again
     assert all(step(reverse=True))
     assert len(ddp._hooks) == n_buckets
+
+
+def test_flat_ddp_order_change_under_gradient_accumulation():
+    """Two micro-batches per update (`set_sync(False)` for the first) with the layer order changing between updates:
+    after the first micro-batch every `.grad` is non-None, so a one-hook-per-bucket completeness check would launch a
+    bucket before the rest of its gradients of the LAST backward have accumulated.  Accumulation keeps the counting hooks
+    (one per parameter), and the accumulated gradients equal the plain module's for every order."""
+    sys.path.insert(0, ROOT)
+    from imgadapointr_amd.utils.flat_ddp import FlatDDP
+    torch.manual_seed(4)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.f = nn.ModuleList([nn.Linear(6, 6) for _ in range(6)])
+
+        def forward(self, x, reverse=False):
+            for m in (list(self.f)[::-1] if reverse else list(self.f)):
+                x = torch.tanh(m(x))
+            return x
+
+    net, ref = Net(), Net()
+    ref.load_state_dict(net.state_dict())
+    ddp = FlatDDP(net, bucket_mb=0.0003)
+    xs = [torch.randn(5, 6), torch.randn(5, 6)]
+
+    def update(reverse, accumulate=True):
+        ddp.zero_grad()
+        ref.zero_grad(set_to_none=True)
+        batches = xs if accumulate else xs[:1]
+        for i, x in enumerate(batches):
+            ddp.set_sync(i + 1 == len(batches))
+            ddp(x, reverse).square().sum().backward()
+            ref(x, reverse).square().sum().backward()
+        ddp.finalize()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7), float((p.grad - q.grad).abs().max())
+
+    n_params = len(list(net.parameters()))
+    update(False, accumulate=False)                 # discovery
+    update(False, accumulate=False)                 # learning step -> slim hooks
+    assert len(ddp._hooks) == len(ddp._buckets) and not ddp._learning
+    update(False)                                   # first accumulated update: back to one counting hook per parameter
+    assert len(ddp._hooks) == n_params and ddp._learning
+    for reverse in (True, False, True):
+        update(reverse)
+        assert len(ddp._hooks) == n_params          # and it stays there, whatever the order does

@@ -166,3 +166,12 @@ def test_sync_bn_conversion_keeps_the_token_major_head():
     assert len(calls) == 4                                   # two token-major GEMMs per call: not the literal Conv1d path
     assert torch.allclose(got_train, want_train, atol=1e-5) and torch.allclose(got_eval, want_eval, atol=1e-5)
     assert torch.allclose(model2.increase_dim[1].running_mean, rm, atol=1e-6)
+
+
+def test_attention_backward_switch_is_parsed_not_truthy():
+    """PTOPS_ATTN_BWD: 'split' / 'fused' pick the libptops kernels, '0' / 'false' the aten backward, a typo raises."""
+    from imgadapointr_amd.models.Transformer_utils import _parse_attn_bwd
+    assert _parse_attn_bwd("split") == "split" and _parse_attn_bwd("Fused") == "fused"
+    assert _parse_attn_bwd("0") is False and _parse_attn_bwd("false") is False and _parse_attn_bwd("off") is False
+    with pytest.raises(ValueError):
+        _parse_attn_bwd("spilt")

@@ -74,6 +74,17 @@ def test_full_train_step_of_the_fused_families_matches_reference(case):
     print(pc.check_trainstep(case, "cuda"))
 
 
+@pytest.mark.parametrize("case", ["img", "seg"])
+def test_fused_family_train_step_is_bit_reproducible_outside_the_library_branches(case):
+    """Two runs of the same B = 2 `TrainStep` in one process: every gradient that does not belong to the ResNet18 / GDANet
+    (MIOpen) must be bit-identical - the padded-head multihead attention, add + LayerNorm and fusion layers are libptops
+    kernels, and a race in them would show here (round-3 review: separate "MIOpen picked another kernel" from "a libptops
+    kernel races")."""
+    n, lib_differ = pc.check_trainstep_reproducible(case, "cuda")
+    assert n > 300
+    print(f"{n} tensors bit-identical; library-branch tensors that differ between the runs: {len(lib_differ)}")
+
+
 def test_multi_view_batch_equals_separate_views():
     print(pc.check_multi_view("cuda", views=3))
 

@@ -178,3 +178,45 @@ def test_clip_adamw_host_path_matches_torch():
     for p, q in zip(a, b):
         assert torch.equal(p, q)
         assert set(our.state[q]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_batch_size_of_the_image_yaml_under_several_ranks():
+    """cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml carries the reference's placeholder `total_bs: 1` (its
+    distributed loader hard-codes 64 per rank, builder.py:19).  A multi-rank launch of that YAML must get a loader, not an
+    assertion: 64 per rank by default, `--total_bs` when given; non-divisible explicit batches stay an error."""
+    from types import SimpleNamespace
+    from imgadapointr_amd.tools import builder
+    from imgadapointr_amd.utils.config import cfg_from_yaml_file
+    from imgadapointr_amd.utils import parser
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        cfg = cfg_from_yaml_file("cfgs/ImgPCN_models/ImgResNetEncAdaPoinTrVariableLoss.yaml")
+    finally:
+        os.chdir(cwd)
+    assert cfg.total_bs == 1
+    assert builder.resolve_batch_size(cfg.total_bs, 8, True) == builder.REFERENCE_DISTRIBUTED_BS == 64
+    assert builder.resolve_batch_size(cfg.total_bs, 8, True, override=128) == 16
+    assert builder.resolve_batch_size(cfg.total_bs, 1, False) == 1
+    assert builder.resolve_batch_size(cfg.total_bs, 1, False, override=16) == 16
+    assert builder.resolve_batch_size(256, 8, True) == 32
+    with pytest.raises(AssertionError):
+        builder.resolve_batch_size(12, 8, True)
+    with pytest.raises(AssertionError):
+        builder.resolve_batch_size(1, 8, True, override=12)
+    assert parser.build_parser().parse_args(['--total_bs', '128']).total_bs == 128
+    # and the loader a rank of a 2-rank job builds from it (synthetic dataset in place of the PCN tree)
+    from imgadapointr_amd.utils.config import EasyDict
+    ds = EasyDict(_base_=EasyDict(NAME='SyntheticPCN', N_POINTS=64, N_PARTIAL=32, LENGTH=256),
+                  others=EasyDict(subset='train', bs=builder.resolve_batch_size(cfg.total_bs, 2, True)))
+    import torch.distributed as dist
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29653', rank=0, world_size=1)
+    try:
+        sampler, loader = builder.dataset_builder(SimpleNamespace(distributed=True, num_workers=0), ds)
+        assert loader.batch_size == 64 and sampler is not None
+    finally:
+        if created:
+            dist.destroy_process_group()
