@@ -236,6 +236,67 @@ def _same_device(*ts):
     return d
 
 
+# ---- HIP-graph capture of a whole step (utils/graph_runner.py::GraphedTrainStep) ------------------------------------
+# A captured launch sequence is replayed without running this module again, so everything the host decides per call must
+# be frozen for the life of the graph, and every buffer whose address is baked into it must be owned by the graph:
+#   * `private_state()` gives the warm-up steps and the capture their OWN workspace tables (fold arena, column-sum /
+#     weight-gradient / Chamfer-reduction workspaces, device problem tables); the caller keeps the returned object alive
+#     as long as the graph, and nothing the eager path does afterwards can free or recycle those buffers;
+#   * inside `capturing()` the Chamfer policy neither probes nor reads statistics back (its current per-shape choice is
+#     used as it stands), and host tables that a captured copy node reads (the pointer table of the grouped weight
+#     gradients) are pinned and kept alive by the same object.
+_capture = None               # None, or the PrivateState of the capture in progress
+
+
+class PrivateState:
+    """The workspace tables of one graphed step (see above).  A context manager: inside, this module's tables are these."""
+    _NAMES = ("_colsum_ws", "_fold_arena", "_wgrad_ws", "_wgrad_tables", "_chamfer_reduce_ws")
+
+    def __init__(self):
+        self.tables = {n: {} for n in self._NAMES}
+        self.keepalive = []            # pinned host tables, plans: whatever a captured node reads
+        self._saved = None
+
+    def __enter__(self):
+        g = globals()
+        assert self._saved is None, "PrivateState is not re-entrant"
+        if _fold_deferred or _fold_keepalive or _wgrad_queue:
+            raise PtopsError("private_state: entered while gradients are queued (inside deferred_folds)")
+        self._saved = {n: g[n] for n in self._NAMES}
+        for n in self._NAMES:
+            g[n] = self.tables[n]
+        return self
+
+    def __exit__(self, *exc):
+        g = globals()
+        for n in self._NAMES:
+            g[n] = self._saved[n]
+        self._saved = None
+        return False
+
+
+def private_state():
+    return PrivateState()
+
+
+class capturing:
+    """Marks a stream capture in progress (entered inside `torch.cuda.graph`, inside the PrivateState `state`)."""
+
+    def __init__(self, state):
+        self.state = state
+
+    def __enter__(self):
+        global _capture
+        assert _capture is None
+        _capture = self.state
+        return self
+
+    def __exit__(self, *exc):
+        global _capture
+        _capture = None
+        return False
+
+
 # ------------------------------------------------------------------------------------------
 CHAMFER_AUTO, CHAMFER_BRUTE, CHAMFER_SWEEP, CHAMFER_MFMA = 0, 1, 2, 3
 CHAMFER_MFMA_MIN_PAIRS = 1 << 32        # PTOPS_CHAMFER_MFMA_MIN_PAIRS of include/ptops.h
@@ -297,6 +358,12 @@ class _ChamferPolicy:
             algos.append(ladders[d][min(st["level"][d], len(ladders[d]) - 1)])
         return algos, st
 
+    def frozen(self, key, sweep_ok, pairs):
+        """The choice `choose` would make now, without touching the state: what a captured launch sequence bakes in."""
+        st = self.state.get(key, dict(level=[0, 0], left=[0, 0]))
+        ladder = self._ladder(sweep_ok, pairs)
+        return [ladder[min(st["level"][d] if st["left"][d] > 0 else 0, len(ladder) - 1)] for d in range(2)]
+
     @staticmethod
     def record(st, stats_dev, algos):
         if st is None or st["pending"] is not None:
@@ -339,7 +406,9 @@ def chamfer_forward(xyz1, xyz2, algorithm=CHAMFER_AUTO):
         wsb = lib.ptops_chamfer_forward_workspace_bytes(B, n, m)
         ws = torch.empty(((wsb + 15) // 16 * 2,), dtype=torch.int64, device=dev) if wsb else None
         stats = st = None
-        if algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
+        if algos == [CHAMFER_AUTO, CHAMFER_AUTO] and _capture is not None:
+            algos = _chamfer_policy.frozen((dev.index, B, n, m), bool(lib.ptops_chamfer_sweep_available(B, n, m)), B * n * m)
+        elif algos == [CHAMFER_AUTO, CHAMFER_AUTO]:
             algos, st = _chamfer_policy.choose((dev.index, B, n, m), bool(lib.ptops_chamfer_sweep_available(B, n, m)),
                                                B * n * m)
             if st["pending"] is None and any(a in (CHAMFER_SWEEP, CHAMFER_MFMA) for a in algos):
@@ -827,6 +896,8 @@ def _fold_workspace(dev, stream, need, *outs):
     if slot is None or slot[1] + need > slot[0].numel():
         if slot is not None:
             _fold_keepalive.append(slot[0])             # still referenced by queued folds
+            if _capture is not None:
+                _capture.keepalive.append(slot[0])      # ... and by the captured launches, for the life of the graph
         slot = [torch.empty((max(256 << 20, 2 * need),), dtype=torch.uint8, device=dev), 0]
         _fold_arena[dev.index] = slot
     ptr = ctypes.c_void_p(slot[0].data_ptr() + slot[1])
@@ -1005,7 +1076,14 @@ def wgrad_flush():
                 raise PtopsError("wgrad_flush: unsupported problem in the queue")
             host = np.zeros(need, dtype=np.uint8)
             lib.ptops_wgrad_group_plan(mnk.ctypes.data, flags.ctypes.data, n, 0, host.ctypes.data, need)
-            plan = (host, torch.from_numpy(host).to(dev), int(lib.ptops_wgrad_group_workspace_bytes(host.ctypes.data)))
+            if _capture is not None:                          # a captured copy node: pinned source, kept alive
+                pinned = torch.from_numpy(host).pin_memory()
+                _capture.keepalive.append(pinned)
+                dev_plan = torch.empty(need, dtype=torch.uint8, device=dev)
+                dev_plan.copy_(pinned, non_blocking=True)
+            else:
+                dev_plan = torch.from_numpy(host).to(dev)
+            plan = (host, dev_plan, int(lib.ptops_wgrad_group_workspace_bytes(host.ctypes.data)))
             if len(_wgrad_plans) > 16:
                 _wgrad_plans.clear()
             _wgrad_plans[key] = plan
@@ -1033,9 +1111,14 @@ def wgrad_flush():
                 rows_dev = tables.pop(next(iter(tables)))       # its last readers)
             else:
                 rows_dev = torch.empty((n, 9), dtype=torch.int64, device=dev)
-            rows_dev.copy_(torch.from_numpy(rows).pin_memory(), non_blocking=True)
+            pinned = torch.from_numpy(rows).pin_memory()
+            rows_dev.copy_(pinned, non_blocking=True)
+            if _capture is not None:                            # the copy node reads this table at every replay
+                _capture.keepalive.append(pinned)
             tables[sig] = rows_dev
             wgrad_table_uploads[0] += 1
+        if _capture is not None:
+            _capture.keepalive.append(plan)
         _call("ptops_gemm_f32_split3_wgrad_grouped", ctypes.c_void_p(rows.ctypes.data), _ptr(rows_dev), n,
               ctypes.c_void_p(host_plan.ctypes.data), _ptr(dev_plan), _ptr(ws), ws.numel(), handle)
         # `queue` (operands, output storages) dies here: the launches are queued behind it in stream order

@@ -77,8 +77,9 @@ class TrainStep:
             for p in self._every_param:
                 p.grad = None
 
-    def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None):
-        """`denoise_noise` ([B,64,3]) replaces the random jitter of the denoise seeds (fixture-driven parity runs)."""
+    def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None, _update=None):
+        """`denoise_noise` ([B,64,3]) replaces the random jitter of the denoise seeds (fixture-driven parity runs).
+        `_update` (utils/graph_runner.py::GraphedTrainStep, inside a stream capture) replaces clip + optimizer step."""
         if denoise_noise is None:
             ret = self.model(partial, *extra)
         else:
@@ -98,7 +99,9 @@ class TrainStep:
                 self.ddp.finalize()
             if self.before_update is not None:
                 self.before_update()
-            if hasattr(self.optimizer, "step_clipped") and FUSED_CLIP_ADAMW:
+            if _update is not None:
+                _update()
+            elif hasattr(self.optimizer, "step_clipped") and FUSED_CLIP_ADAMW:
                 self.optimizer.step_clipped(self.clip)          # clip + AdamW of all parameters, three launches
             else:
                 torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], self.clip, norm_type=2)

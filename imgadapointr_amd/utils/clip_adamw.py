@@ -57,7 +57,7 @@ class ClipAdamW(torch.optim.AdamW):
         super().step()
         return norm
 
-    def _supported(self, params):
+    def _supported(self, params, check_grads=True):
         if not params or _native.backend_for_testing() is not None:
             return False
         dev = params[0].device
@@ -67,8 +67,8 @@ class ClipAdamW(torch.optim.AdamW):
             if g.get("amsgrad") or g.get("maximize") or g.get("capturable"):
                 return False
         return all(p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous()
-                   and p.grad.dtype == torch.float32 and not p.grad.is_sparse and p.grad.is_contiguous()
-                   and p.grad.device == dev for p in params)
+                   and (not check_grads or (p.grad.dtype == torch.float32 and not p.grad.is_sparse
+                                            and p.grad.is_contiguous() and p.grad.device == dev)) for p in params)
 
     # ------------------------------------------------------------------ the plan: everything that does not change per step
     def _make_plan(self, params, group_of):
@@ -119,40 +119,33 @@ class ClipAdamW(torch.optim.AdamW):
         }
         return plan
 
-    @torch.no_grad()
-    def step_clipped(self, max_norm):
-        """clip_grad_norm_(all parameters with a gradient, max_norm) + step().  -> the gradient norm (0-dim tensor)."""
+    def _with_grad(self):
         params, group_of = [], []
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 if p.grad is not None:
                     params.append(p)
                     group_of.append(gi)
-        key = tuple(id(p) for p in params)
-        if self._plan is None or self._plan["key"] != key:              # the full eligibility check once per parameter set
-            if not self._supported(params):
-                self._sync_steps()
-                self._plan = None
-                return self._stock(max_norm)
-        if (self._plan is None or self._plan["key"] != key
-                or any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(params[:4], self._plan["rows"][:4, 2]))):
-            self._sync_steps()                        # the old plan's counters go back into the state first
-            self._plan = self._make_plan(params, group_of)
-        plan = self._plan
-        self._opt_called = True                        # what LRScheduler's wrapper around step() records
-        # the hooks `Optimizer.step` would run (register_step_pre_hook / register_step_post_hook, global ones included)
-        from torch.optim.optimizer import _global_optimizer_post_hooks, _global_optimizer_pre_hooks
-        for hook in list(_global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
-            hook(self, (), {})
+        return params, group_of
+
+    def _activate(self, plan):
+        """Make `plan` the current one; the step counters travel through state[p]["step"] (torch's format)."""
+        if self._plan is not plan:
+            self._sync_steps()
+            plan["steps"] = torch.stack([self.state[p]["step"].detach().reshape(()).to("cpu", torch.float64)
+                                         for p in plan["params"]]).numpy().copy()
+            self._plan = plan
+
+    def _fill_and_upload(self, plan):
+        """Advance the step counters, write this step's hyper-parameters into the table and send it to the device
+        (asynchronously, on the current stream, from a ring of pinned buffers)."""
         rows = plan["rows"]
-        rows[:, 1] = [p.grad.data_ptr() for p in params]
         plan["steps"] += 1.0
         steps = plan["steps"]
         beta1, beta2 = self.param_groups[0]["betas"]
-        eps = self.param_groups[0]["eps"]
         lr = np.array([g["lr"] for g in self.param_groups], dtype=np.float32)[plan["group_of"]]
         wd = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float32)[plan["group_of"]]
-        f32 = rows.view(np.float32).reshape(len(params), _ROW // 4)
+        f32 = rows.view(np.float32).reshape(len(plan["params"]), _ROW // 4)
         f32[:, 10] = lr
         f32[:, 11] = wd
         f32[:, 12] = (1.0 - beta1 ** steps).astype(np.float32)
@@ -166,11 +159,93 @@ class ClipAdamW(torch.optim.AdamW):
         plan["rows_dev"].copy_(host, non_blocking=True)
         plan["rows_event"][slot].record()
         plan["rows_used"][slot] = True
-        _native.adamw_clip_step(plan["rows_dev"], len(params), plan["chunks_dev"], plan["n_chunks"],
-                                float(max_norm) if max_norm else 0.0, beta1, beta2, eps, plan["partial"], plan["norm_coef"])
+
+    def _launch(self, plan, max_norm):
+        beta1, beta2 = self.param_groups[0]["betas"]
+        _native.adamw_clip_step(plan["rows_dev"], len(plan["params"]), plan["chunks_dev"], plan["n_chunks"],
+                                float(max_norm) if max_norm else 0.0, beta1, beta2, self.param_groups[0]["eps"],
+                                plan["partial"], plan["norm_coef"])
+
+    def _pre_hooks(self):
+        # the hooks `Optimizer.step` would run (register_step_pre_hook / register_step_post_hook, global ones included)
+        from torch.optim.optimizer import _global_optimizer_pre_hooks
+        for hook in list(_global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
+            hook(self, (), {})
+
+    def _post_hooks(self):
+        from torch.optim.optimizer import _global_optimizer_post_hooks
+        self._opt_called = True                        # what LRScheduler's wrapper around step() records
         for hook in list(self._optimizer_step_post_hooks.values()) + list(_global_optimizer_post_hooks.values()):
             hook(self, (), {})
+
+    @torch.no_grad()
+    def step_clipped(self, max_norm):
+        """clip_grad_norm_(all parameters with a gradient, max_norm) + step().  -> the gradient norm (0-dim tensor)."""
+        params, group_of = self._with_grad()
+        key = tuple(id(p) for p in params)
+        stale = self._plan is None or self._plan["key"] != key or self._plan.get("graph", False)
+        if stale:                                                       # the full eligibility check once per parameter set
+            if not self._supported(params):
+                self._sync_steps()
+                self._plan = None
+                return self._stock(max_norm)
+        if stale or any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(params[:4], self._plan["rows"][:4, 2])):
+            self._sync_steps()                        # the old plan's counters go back into the state first
+            self._plan = self._make_plan(params, group_of)
+        plan = self._plan
+        self._pre_hooks()
+        plan["rows"][:, 1] = [p.grad.data_ptr() for p in params]
+        self._fill_and_upload(plan)
+        self._launch(plan, max_norm)
+        self._post_hooks()
         return plan["norm_coef"][0]
+
+    # ------------------------------------------------------------------ the same step inside a captured HIP graph
+    # (utils/graph_runner.py::GraphedTrainStep).  A graph bakes in addresses, not values: the kernels read everything
+    # that changes per step (learning rate, weight decay, bias corrections) from the device table, which is rewritten
+    # BEFORE each replay by an ordinary stream-ordered copy; the gradients live at fixed addresses of the graph's pool.
+    @torch.no_grad()
+    def graph_plan(self, params):
+        """Before the capture: the plan for `params` (those that will hold a gradient), or None if the fused step does
+        not support them."""
+        group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        with_grad = [p for g in self.param_groups for p in g["params"] if any(p is q for q in params)]
+        if len(with_grad) != len(params) or not with_grad:
+            return None
+        if not self._supported(with_grad, check_grads=False):      # the gradients' layout is checked inside the capture
+            return None
+        self._sync_steps()
+        self._plan = None
+        plan = self._make_plan(with_grad, [group_of[id(p)] for p in with_grad])
+        plan["graph"] = True
+        return plan
+
+    @torch.no_grad()
+    def graph_capture_step(self, plan, max_norm):
+        """Inside the capture, where `step_clipped` would run: notes the (fixed) gradient addresses and records the three
+        launches.  -> the gradient norm (a tensor that every replay overwrites)."""
+        params, _ = self._with_grad()
+        if tuple(id(p) for p in params) != plan["key"]:
+            raise RuntimeError("ClipAdamW.graph_capture_step: the parameters holding a gradient differ from the plan's")
+        for p in params:
+            if not (p.grad.dtype == torch.float32 and p.grad.is_contiguous() and not p.grad.is_sparse):
+                raise RuntimeError("ClipAdamW.graph_capture_step: unsupported gradient layout")
+        plan["grad_ptrs"] = np.array([p.grad.data_ptr() for p in params], dtype=np.uint64)
+        self._launch(plan, max_norm)
+        return plan["norm_coef"][0]
+
+    @torch.no_grad()
+    def graph_before_replay(self, plan):
+        """Before every replay (stream-ordered in front of it): counters, hyper-parameters and table upload."""
+        if any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(plan["params"][:4], plan["rows"][:4, 2])):
+            raise RuntimeError("ClipAdamW: the optimizer state was replaced (load_state_dict) under a captured step")
+        self._activate(plan)
+        self._pre_hooks()
+        plan["rows"][:, 1] = plan["grad_ptrs"]
+        self._fill_and_upload(plan)
+
+    def graph_after_replay(self, plan):
+        self._post_hooks()
 
     def uniform_hyperparameters(self):
         """betas / eps must be the same in every group for the fused path (they are kernel arguments)."""

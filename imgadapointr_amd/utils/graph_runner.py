@@ -165,3 +165,197 @@ class GraphedForward:
             graph.replay()
             self.replays += 1
             return rebuild([t.clone() for t in flat])     # the static outputs are overwritten by the next replay
+
+
+class GraphedTrainStep:
+    """A `tools.runner.TrainStep` whose launches are replayed from one HIP graph per input signature.
+
+    Why: the batch-16 image / segmentation variants (BASELINE configs[2] / [4]) enqueue 1100+ launches of a few
+    microseconds per step and are bound by the host's launch rate (host 24.7 ms vs device 26.8 ms, 44.2 vs 44.7 ms,
+    profiles/round3/host_profile_seg_v1.log); eight ranks sharing one host make that worse.  A replay costs the host one
+    call.
+
+    What a graph bakes in, and how each item is handled:
+      * addresses of inputs -> static input buffers, copied into before each replay;
+      * the optimizer's per-step scalars (lr, weight decay, bias corrections, step count) -> they live in ClipAdamW's
+        device table, rewritten by an ordinary stream-ordered copy before each replay (`graph_before_replay`); the
+        gradients sit at fixed addresses of the graph's memory pool;
+      * the epoch-dependent coarse-loss weight of the VariableLoss models -> part of the cache key (one capture per value);
+      * the denoise jitter -> drawn eagerly before the replay with exactly the call the model would make (same generator
+        consumption as the eager step), handed in as a static input; other RNG consumers (GDANet's dropout) use torch's
+        graph-safe generator state;
+      * libptops' host-side decisions -> `_native.private_state()` (own workspaces for the life of the graph) and
+        `_native.capturing()` (Chamfer policy frozen at its current per-shape choice, pinned pointer tables kept alive).
+    The first `warmup` calls of a signature run eagerly (they are real training steps) and let the caches settle; the next
+    call captures, and - with `verify` - proves the graph: model, optimizer and RNG state are snapshotted, the replayed
+    step and the eager step are both run from that state and must agree (bit for bit unless the model draws random
+    numbers inside the graph); training continues from the eager result.  Any failure falls back to eager for good, with
+    the reason in `disabled_reason`.
+
+    Not graphed (eager `TrainStep` runs instead): a data-parallel wrapper (its hooks launch collectives from Python),
+    gradient accumulation, a `before_update` callback, CPU tensors, an optimizer without the fused clip + AdamW plan."""
+
+    def __init__(self, step, warmup=3, verify=True, max_graphs=2, enabled=True):
+        self.step = step
+        self.warmup = max(2, int(warmup))
+        self.verify = verify
+        self.max_graphs = max(1, max_graphs)
+        self.enabled = enabled
+        self.disabled_reason = None
+        self.replays = 0
+        self.verified = None            # None until a capture was compared with the eager step: then the largest difference
+        self._seen = {}                 # signature -> eager steps so far
+        self._cache = OrderedDict()
+        self._with_grad = None
+
+    # delegate what the runner touches on a TrainStep
+    @property
+    def optimizer(self):
+        return self.step.optimizer
+
+    @property
+    def model(self):
+        return self.step.model
+
+    def zero_grad(self):
+        self.step.zero_grad()
+
+    def _disable(self, reason):
+        self.enabled = False
+        self.disabled_reason = reason
+        self._cache.clear()
+        _log.warning("GraphedTrainStep: falling back to eager steps (%s)", reason)
+
+    def _eligible(self, tensors):
+        from ..tools import runner
+        s = self.step
+        return (self.enabled and s.ddp is None and s.step_per_update == 1 and s.before_update is None
+                and runner.FUSED_CLIP_ADAMW and hasattr(s.optimizer, "graph_plan") and torch.is_grad_enabled()
+                and s.net.training and input_device(tensors) is not None)
+
+    def _noise(self, partial, extra):
+        """The jitter of the denoise seeds exactly as the trunk draws it (models/AdaPoinTr.py: `empty_like(picked)
+        .normal_(0, 0.01).clamp_(-0.05, 0.05)`, picked = [B * views, denoise_num, 3])."""
+        trunk = getattr(self.step.net, "base_model", None)
+        n = getattr(trunk, "denoise_num", None)
+        if n is None:
+            return None
+        rows = partial.size(0)
+        for t in extra:
+            if isinstance(t, torch.Tensor) and t.dim() == 5:
+                rows *= t.size(1)
+        return torch.empty((rows, n, 3), dtype=partial.dtype, device=partial.device).normal_(mean=0.0, std=0.01).clamp_(-0.05, 0.05)
+
+    def _snapshot(self):
+        opt = self.step.optimizer
+        opt._sync_steps()
+        tensors = [p for p in self.step.net.parameters()] + [b for b in self.step.net.buffers()]
+        for st in opt.state.values():
+            tensors += [v for v in st.values() if isinstance(v, torch.Tensor)]
+        return tensors, [t.detach().clone() for t in tensors], torch.cuda.get_rng_state(tensors[0].device)
+
+    def _restore(self, snap):
+        tensors, saved, rng = snap
+        self.step.optimizer._plan = None        # its host-side step counters are stale now: the state's tensors are the truth
+        with torch.no_grad():
+            for t, s in zip(tensors, saved):
+                t.copy_(s)
+        torch.cuda.set_rng_state(rng, tensors[0].device)
+
+    def _capture(self, tensors, epoch, has_noise, n_extra):
+        """-> cache entry, or None (graphing disabled).  The captured step has NOT run when this returns."""
+        from .. import _native
+        opt = self.step.optimizer
+        device = tensors[0].device
+        plan = opt.graph_plan(self._with_grad)
+        if plan is None:
+            self._disable("the optimizer's fused clip + AdamW step does not support this parameter set")
+            return None
+        state = self._state
+        static = [t.clone() for t in tensors]
+        partial, gt = static[0], static[1]
+        extra = tuple(static[2:2 + n_extra])
+        noise = static[-1] if has_noise else None
+        self.step.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with state, torch.cuda.graph(graph), _native.capturing(state):
+                out = self.step(partial, gt, extra, epoch, noise,
+                                _update=lambda: plan.__setitem__("norm", opt.graph_capture_step(plan, self.step.clip)))
+        except torch.cuda.OutOfMemoryError:
+            raise
+        except (RuntimeError, TypeError) as exc:
+            torch.cuda.synchronize(device)
+            self.step.zero_grad()
+            self._disable(f"capture failed: {type(exc).__name__}: {exc}")
+            return None
+        return dict(static=static, graph=graph, out=out, plan=plan, state=state)
+
+    def _replay(self, entry, tensors):
+        opt = self.step.optimizer
+        for s, t in zip(entry["static"], tensors):
+            s.copy_(t)
+        opt.graph_before_replay(entry["plan"])
+        entry["graph"].replay()
+        opt.graph_after_replay(entry["plan"])
+        self.replays += 1
+        return tuple(t.clone() for t in entry["out"])        # the static outputs are overwritten by the next replay
+
+    def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None):
+        from .. import _native
+        extra = tuple(extra)
+        tensors = [partial, gt] + [t for t in extra]
+        if any(not isinstance(t, torch.Tensor) for t in tensors) or not self._eligible(tensors):
+            return self.step(partial, gt, extra, epoch, denoise_noise)
+        device = partial.device
+        with torch.cuda.device(device):
+            if denoise_noise is None:
+                denoise_noise = self._noise(partial, extra)
+            has_noise = denoise_noise is not None
+            if has_noise:
+                tensors = tensors + [denoise_noise]
+            weight = getattr(self.step.net, "coarse_loss_weight", lambda e: 1.0)(epoch)
+            key = (signature(tensors), float(weight), len(extra), has_noise)
+            entry = self._cache.get(key)
+            if entry is not None:
+                self._cache.move_to_end(key)
+                return self._replay(entry, tensors)
+            if not hasattr(self, "_state"):
+                self._state = _native.private_state()
+            seen = self._seen.get(key, 0)
+            if seen < self.warmup:
+                # eager (real) steps inside the graph's own workspace tables; the last one notes which parameters get gradients
+                self._seen[key] = seen + 1
+                if seen + 1 == self.warmup:
+                    self.step.before_update = lambda: setattr(
+                        self, "_with_grad", [p for p in self.step.params if p.grad is not None])
+                try:
+                    with self._state:
+                        return self.step(partial, gt, extra, epoch, denoise_noise)
+                finally:
+                    self.step.before_update = None
+            entry = self._capture(tensors, epoch, has_noise, len(extra))
+            if entry is None:
+                return self.step(partial, gt, extra, epoch, denoise_noise)
+            if self.verify:
+                snap = self._snapshot()
+                got = self._replay(entry, tensors)
+                after = [p.detach().clone() for p in self.step.params[:8]]
+                torch.cuda.synchronize(device)
+                self._restore(snap)
+                with self._state:
+                    want = self.step(partial, gt, extra, epoch, denoise_noise)
+                diff = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in
+                           list(zip(got, want)) + list(zip(after, [p.detach() for p in self.step.params[:8]])))
+                self.verified = diff
+                if not diff <= self.verify_tolerance:
+                    self._disable(f"the replayed step differs from the eager step by {diff:.3e} (relative)")
+                    return want
+            self._cache[key] = entry
+            while len(self._cache) > self.max_graphs:
+                self._cache.popitem(last=False)       # drops the graph, its memory pool and its workspaces
+            return want if self.verify else self._replay(entry, tensors)
+
+    # relative difference between the replayed and the eager step (losses, first parameters after the update) that the
+    # capture-time check accepts: kernels of this build are deterministic, MIOpen's / in-graph dropout need not be
+    verify_tolerance = 1e-4

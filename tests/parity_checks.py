@@ -439,15 +439,28 @@ def check_baseline_forms(device):
                 dict(NAME='FoldingNet', num_pred=1024, encoder_channel=256),
                 dict(NAME='TopNet', node_feature=8, num_pred=2048, encoder_channel=248, nlevels=6)):
         o64, g64, b64 = run(cfg, False, torch.float64)
-        (o1, g1, b1), (o2, g2, b2) = run(cfg, True, torch.float32), run(cfg, False, torch.float32)
+        # (1) the two forms are the SAME FUNCTION: in float64, where a near-tie of a max-pool arg-max would need a gap below
+        # 1e-16, token-major and literal agree to accumulated double rounding in outputs, buffers and every gradient
+        o64t, g64t, b64t = run(cfg, True, torch.float64)
         scale = float(o64.abs().max())
+        same = dict(out=float((o64t - o64).abs().max()) / scale, grad=grad_err(g64t, g64),
+                    buf=max(float((b64t[n] - b64[n]).abs().max() / (1 + b64[n].abs().max())) for n in b64))
+        assert same["out"] < 1e-10 and same["grad"] < 1e-9 and same["buf"] < 1e-10, (cfg['NAME'], same)
+        # (2) in fp32 each form is judged against float64.  Values: token-major no further than the literal form (1.5x: two
+        # samples of one rounding cloud).  Gradients: only the conditioning envelope - the encoders pool with max over points,
+        # and a near-tie there flips between implementations, boxes and ulp-level input perturbations alike, moving the
+        # encoder's gradient in quantised jumps (measured on the CPU with 1e-7 input perturbations, FoldingNet: 3.9e-4,
+        # 1.5e-3, 3.7e-3 depending on the seed - a float64 arm perturbed the same way jumps to 1.5e-3 too; on GPU boxes
+        # 3.7e-3 or 2.1e-2 for either form).  An ordering of two such samples (round 3's `e_grad[0] <= 1.5 e_grad[1]`)
+        # failed on the box where the literal form drew 3.7e-3 and the token-major one 2.1e-2 (pytest_gpu_r4_v1.log); with
+        # (1) proving identity there is nothing left for it to show.
+        (o1, g1, b1), (o2, g2, b2) = run(cfg, True, torch.float32), run(cfg, False, torch.float32)
         e_out = (float((o1 - o64).abs().max()) / scale, float((o2 - o64).abs().max()) / scale)
         e_grad = (grad_err(g1, g64), grad_err(g2, g64))
         e_buf = max(float((b1[n] - b64[n]).abs().max() / (1 + b64[n].abs().max())) for n in b64)
-        report[cfg['NAME']] = dict(out_vs_f64=e_out, grad_vs_f64=e_grad, buf_vs_f64=e_buf, grad_form_vs_form=grad_err(g1, g2))
-        # the token-major form is as close to float64 as the literal form (1.5x: two samples of one rounding cloud), and
-        # neither is further than the worst conditioning measured (FoldingNet, 2.1e-2) allows
-        assert e_out[0] <= 1.5 * e_out[1] + 1e-6 and e_grad[0] <= 1.5 * e_grad[1] + 1e-6, report
+        report[cfg['NAME']] = dict(f64_form_vs_form=same, out_vs_f64=e_out, grad_vs_f64=e_grad, buf_vs_f64=e_buf,
+                                   grad_form_vs_form=grad_err(g1, g2))
+        assert e_out[0] <= 1.5 * e_out[1] + 1e-6, report
         assert max(e_out) < 5e-4 and max(e_grad) < 6e-2 and e_buf < 1e-5, report
     return report
 
