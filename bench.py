@@ -37,6 +37,7 @@ from imgadapointr_amd.tools.runner import TrainStep  # noqa: E402
 from imgadapointr_amd.utils.config import cfg_from_yaml_file  # noqa: E402
 from imgadapointr_amd.utils.flat_ddp import FlatDDP  # noqa: E402
 from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm  # noqa: E402
+from imgadapointr_amd.utils.graph_runner import GraphedTrainStep  # noqa: E402
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (same table; 2:1 sparsity figures are not used)
@@ -444,6 +445,74 @@ def cpu_baseline(cfg, spec, budget_s=20.0):
             "ms_per_step": round(dt / n * 1e3, 1)}
 
 
+def make_workload(which, device, batch=None, views=1, seed=0, wrap=None):
+    """Model (random init), production TrainStep and one synthetic batch of a model family, resident on `device`."""
+    spec = MODELS[which]
+    B = batch or spec["batch"]
+    cfg = load_cfg(which)
+    torch.manual_seed(0)                     # identical weights on every rank
+    model = build_model_from_cfg(cfg.model).to(device)
+    if spec["cls"]:                          # the runner freezes the segmentator (tools/runner.py:55-66)
+        for p in model.base_model.segmentator.parameters():
+            p.requires_grad = False
+    model.train()
+    wrapped = wrap(model) if wrap is not None else model
+    optimizer = builder.build_optimizer(wrapped, cfg)
+    step = TrainStep(wrapped, optimizer, getattr(cfg, "grad_norm_clip", 10), 1)
+    torch.manual_seed(seed)                  # per-rank data, main.py:57 of the reference
+    partial = (torch.rand(B, N_PARTIAL, 3) - 0.5).to(device)
+    gt = (torch.rand(B, N_GT, 3) - 0.5).to(device)
+    extra = []
+    if spec["img"]:
+        shape = (B, 3, 224, 224) if views == 1 else (B, views, 3, 224, 224)
+        extra.append(torch.rand(*shape).to(device))
+    if spec["cls"]:
+        cls_vec = torch.zeros(B, 16)
+        cls_vec[torch.arange(B), torch.tensor([0, 4, 8, 15])[torch.arange(B) % 4]] = 1.0    # SegImgPCNDataset.py:5-12
+        extra.append(cls_vec.to(device))
+    return model, cfg, spec, step, (partial, gt, tuple(extra)), B
+
+
+def time_steps(step, batch, steps, warmup):
+    partial, gt, extra = batch
+    for _ in range(warmup):
+        step(partial, gt, extra)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step(partial, gt, extra)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, last
+
+
+def run_variant(which, device, steps=10, warmup=5, note=lambda m: None):
+    """One of BASELINE's other single-GPU configurations, timed after the headline region so that the driver's JSON
+    carries it: `steps` eager train steps, then the same step replayed from a HIP graph (GraphedTrainStep: 3 eager steps
+    in its own workspaces, capture, a capture-time check against the eager step, then `steps` timed replays).  `value` is
+    the graphed rate when the graph passed its check, else the eager rate."""
+    model, cfg, spec, step, batch, B = make_workload(which, device)
+    eager_s, _ = time_steps(step, batch, steps, warmup)
+    note(f"variant {which}: eager {eager_s * 1e3:.2f} ms/step")
+    gstep = GraphedTrainStep(step, warmup=3, verify=True)
+    graph_s, last = time_steps(gstep, batch, steps, 3 + 1 + 2)
+    graphed = gstep.enabled and gstep.replays >= steps
+    note(f"variant {which}: graphed {graph_s * 1e3:.2f} ms/step (enabled={gstep.enabled}, capture check {gstep.verified})")
+    best = graph_s if graphed else eager_s
+    out = {"metric": f"clouds/sec (train step, bs={B}/GPU), {spec['name']} PCN 2048->16384", "value": round(B / best, 3),
+           "unit": "clouds/s", "ms_per_step": round(best * 1e3, 3), "steps": steps, "n_gpus": 1, "dtype": "f32",
+           "data": "synthetic", "graphed": graphed, "eager_ms_per_step": round(eager_s * 1e3, 3),
+           "graphed_ms_per_step": round(graph_s * 1e3, 3) if graphed else None,
+           "graph_capture_check_max_rel_diff": gstep.verified, "graph_disabled_reason": gstep.disabled_reason,
+           "last_losses_x1000": [round(float(x) * 1000, 4) for x in last],
+           "config": {"workload": f"{spec['name']} {spec['yaml']}, PCN 2048->16384, bs={B}/GPU"
+                                  + (", one 3x224x224 render per sample" if spec["img"] else "")
+                                  + (", 16-class one-hot + frozen GDANet segmentator" if spec["cls"] else "")
+                                  + f", full train step (BASELINE {spec['config']})"}}
+    del gstep, step, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,6 +527,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="clouds (objects) per GPU; default 32 for adapointr, 16 for img / seg (BASELINE.json configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step from a HIP graph (GraphedTrainStep; one process, no data-parallel wrapper). "
+                         "The per-kernel roofline probes are Python-side and see nothing of a replay, so they are off")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` block (configs[2] / [4] at bs 16, eager and graphed, 10 timed steps each) that "
+                         "the default one-GPU run appends after the headline region")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="leave the GEMM kernel choice to the library default")
     args = ap.parse_args()
 
@@ -490,37 +565,19 @@ def main():
     gemm = "library default" if args.no_gemm_tuning else enable_tuned_gemm()
 
     spec = MODELS[args.model]
-    if args.batch is None:
-        args.batch = spec["batch"]
     if args.views != 1 and not spec["img"]:
         raise SystemExit("--views needs a model with an image branch (--model img | seg)")
-    cfg = load_cfg(args.model)
-    torch.manual_seed(0)                     # identical weights on every rank
-    model = build_model_from_cfg(cfg.model).to(device)
-    if spec["cls"]:                          # the runner freezes the segmentator (tools/runner.py:55-66)
-        for p in model.base_model.segmentator.parameters():
-            p.requires_grad = False
-    model.train()
     # PTOPS_BENCH_FORCE_DDP=1 wraps the model at N=1 too (hooks + bucket packing, no collective): a way to see
     # the data-parallel bookkeeping overhead on a one-GPU box.  Never the default.
-    wrapped = FlatDDP(model, single_rank_collectives=single_rank_rccl) if (world > 1 or force_ddp) else model
-    optimizer = builder.build_optimizer(wrapped, cfg)
-    step = TrainStep(wrapped, optimizer, getattr(cfg, "grad_norm_clip", 10), 1)
-
-    torch.manual_seed(0 + rank)              # per-rank data, main.py:57 of the reference
-    B = args.batch
-    partial = (torch.rand(B, N_PARTIAL, 3) - 0.5).to(device)
-    gt = (torch.rand(B, N_GT, 3) - 0.5).to(device)
-    extra = []
-    if spec["img"]:
-        shape = (B, 3, 224, 224) if args.views == 1 else (B, args.views, 3, 224, 224)
-        extra.append(torch.rand(*shape).to(device))
-    if spec["cls"]:
-        cls_vec = torch.zeros(B, 16)
-        cls_vec[torch.arange(B), torch.tensor([0, 4, 8, 15])[torch.arange(B) % 4]] = 1.0    # SegImgPCNDataset.py:5-12
-        extra.append(cls_vec.to(device))
-    extra = tuple(extra)
+    wrap = (lambda m: FlatDDP(m, single_rank_collectives=single_rank_rccl)) if (world > 1 or force_ddp) else None
+    model, cfg, spec, step, (partial, gt, extra), B = make_workload(args.model, device, args.batch, args.views, rank, wrap)
+    args.batch = B
     samples = B * args.views
+    if args.graph:
+        if wrap is not None:
+            raise SystemExit("--graph: the data-parallel wrapper launches collectives from Python hooks; one process only")
+        step = GraphedTrainStep(step, warmup=3, verify=True)
+        args.warmup = max(args.warmup, 3 + 1 + 1)
 
     probe = ChamferProbe(N_GT, N_GT)
     _native.chamfer_forward = probe
@@ -547,7 +604,7 @@ def main():
             note("first step done")
     barrier()
     note("timed region")
-    probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = True
+    probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = not args.graph
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -599,6 +656,18 @@ def main():
             "roofline_gemm": gprobe.summary(),
             "roofline_primitives": pprobe.summary(),
         }
+        if args.graph:
+            out["graphed"] = {"enabled": step.enabled, "replays": step.replays, "capture_check_max_rel_diff": step.verified,
+                              "disabled_reason": step.disabled_reason}
+        if world == 1 and args.model == "adapointr" and args.views == 1 and not args.no_variants and not force_ddp:
+            # the other single-GPU configurations of BASELINE.json, so that the driver's record carries them
+            del step, model
+            torch.cuda.empty_cache()
+            out["variants"] = {w: run_variant(w, device, note=note) for w in ("img", "seg", "adapointr")}
+            out["variants"]["note"] = ("10 timed steps each after the headline region, one process: eager TrainStep, then the same "
+                                       "step replayed from a HIP graph (utils/graph_runner.py::GraphedTrainStep, checked against "
+                                       "the eager step at capture time); `adapointr` = the headline workload replayed, for "
+                                       "comparison with the eager headline above (which carries the per-kernel probes)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, spec)
         print(json.dumps(out), flush=True)

@@ -244,7 +244,10 @@ class GraphedTrainStep:
         for t in extra:
             if isinstance(t, torch.Tensor) and t.dim() == 5:
                 rows *= t.size(1)
-        return torch.empty((rows, n, 3), dtype=partial.dtype, device=partial.device).normal_(mean=0.0, std=0.01).clamp_(-0.05, 0.05)
+        # `picked` is the transpose of a contiguous [rows, 3, n] gather and `empty_like` keeps that layout; the generator
+        # fills in memory order, so the same layout is needed for the same numbers
+        return torch.empty((rows, 3, n), dtype=partial.dtype, device=partial.device).normal_(
+            mean=0.0, std=0.01).clamp_(-0.05, 0.05).transpose(1, 2)
 
     def _snapshot(self):
         opt = self.step.optimizer
