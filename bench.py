@@ -23,7 +23,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see imgadapointr_amd/__init__.py
+
+import torch  # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

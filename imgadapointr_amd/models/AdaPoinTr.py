@@ -54,7 +54,7 @@ class _BatchNormRowsLeakyReLU(torch.autograd.Function):
 
 def _linear_tokens(x, weight, bias):
     """F.linear on [rows, C]; on the GPU path through _LinearFn (streaming bias-gradient column sum)."""
-    if (x.is_cuda and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
+    if (x.is_cuda and x.dtype == torch.float32 and bias is not None and weight.size(0) % 4 == 0 and torch.is_grad_enabled()
             and _native.backend_for_testing() is None and x.size(0) >= 2048):
         return _LinearFn.apply(x, weight, bias)
     if torch.is_grad_enabled():                                  # plain autograd path: see _native.deferred_folds

@@ -8,7 +8,9 @@
 import os
 import time
 
-import torch
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see imgadapointr_amd/__init__.py
+
+import torch  # noqa: E402
 
 from imgadapointr_amd.tools import builder
 from imgadapointr_amd.tools.runner import run_net, test_net

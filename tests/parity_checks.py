@@ -499,24 +499,30 @@ class _FixedDropout(torch.nn.Module):
 
 class _Pinned:
     """Library choices that are free to differ from run to run, pinned for the length of a parity run: MIOpen's
-    per-process search (`benchmark`) off and its deterministic algorithms on."""
+    per-process search (`benchmark`) off, its deterministic algorithms on, ATen's deterministic scatter forms on."""
 
     def __enter__(self):
         b = torch.backends.cudnn
-        self.saved = (b.deterministic, b.benchmark)
+        self.saved = (b.deterministic, b.benchmark, torch.are_deterministic_algorithms_enabled(),
+                      torch.is_deterministic_algorithms_warn_only_enabled())
         b.deterministic, b.benchmark = True, False
+        # ATen's scatter / index_add / gather-backward kernels add with float atomics in arrival order unless told otherwise
+        # (GDANet's feature-space neighbourhoods and the normals go through them); warn_only: an op without a
+        # deterministic form is reported, not refused
+        torch.use_deterministic_algorithms(True, warn_only=True)
         return self
 
     def __exit__(self, *exc):
-        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = self.saved
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = self.saved[:2]
+        torch.use_deterministic_algorithms(self.saved[2], warn_only=self.saved[3])
 
 
 def prepare_trainstep(case, device, replay_scores=True):
     """Model, production `TrainStep`, inputs and fixture of a train-step case with every recorded RNG consumer and chaotic
     decision of the reference's forward replayed: the denoise jitter (passed as `denoise_noise`), the two Dropout(0.4)
-    keep-masks of the train-mode GDANet (GDANet_ptseg.py:59-61) and — round 4 — the query-ranking scores
+    keep-masks of the train-mode GDANet (GDANet_ptseg.py:59-61) and — round 4 — the query ranking
     (AdaPoinTr.py:119-121: the 512-of-768 selection; two scores closer than rounding swap places between implementations).
-    The scores are replayed by a forward hook on the `query_ranking` module, whose parameters receive no gradient in
+    The reference's order is replayed by a forward hook on the `query_ranking` module, whose parameters receive no gradient in
     either implementation (argsort is not differentiable), so nothing on the product side knows about it."""
     from golden_util import trainstep_inputs
     from imgadapointr_amd.tools import builder
@@ -541,7 +547,13 @@ def prepare_trainstep(case, device, replay_scores=True):
             mask = np.unpackbits(g[f"dropout_mask_{i}"])[:int(np.prod(shape))].reshape(shape).astype(np.float32)
             setattr(model.base_model.segmentator, name, _FixedDropout(t(mask, device), 0.4))
     if replay_scores:
-        scores = t(g["query_scores"], device).unsqueeze(-1)
+        # a tie-free surrogate with exactly the reference's order: the Sigmoid of query_ranking leaves EXACT ties between
+        # different proposals (img fixture: smallest gap inside the top 512 is 0.0), and how an argsort orders ties is the
+        # implementation's business (CPU and GPU sorts differ)
+        order = torch.from_numpy(g["query_order"].astype(np.int64))
+        scores = torch.empty(order.shape, dtype=torch.float32)
+        scores.scatter_(1, order, (1.0 - torch.arange(order.size(1), dtype=torch.float32) / 1024.0).expand_as(scores))
+        scores = scores.unsqueeze(-1).to(device)
         model.base_model.query_ranking.register_forward_hook(lambda m, a, o: scores.to(o.dtype))
 
     def run():
