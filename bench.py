@@ -504,7 +504,7 @@ def run_variant(which, device, steps=10, warmup=5, note=lambda m: None):
            "unit": "clouds/s", "ms_per_step": round(best * 1e3, 3), "steps": steps, "n_gpus": 1, "dtype": "f32",
            "data": "synthetic", "graphed": graphed, "eager_ms_per_step": round(eager_s * 1e3, 3),
            "graphed_ms_per_step": round(graph_s * 1e3, 3) if graphed else None,
-           "graph_capture_check_max_rel_diff": gstep.verified, "graph_disabled_reason": gstep.disabled_reason,
+           "graph_capture_check": gstep.verified, "graph_disabled_reason": gstep.disabled_reason,
            "last_losses_x1000": [round(float(x) * 1000, 4) for x in last],
            "config": {"workload": f"{spec['name']} {spec['yaml']}, PCN 2048->16384, bs={B}/GPU"
                                   + (", one 3x224x224 render per sample" if spec["img"] else "")
@@ -659,7 +659,7 @@ def main():
             "roofline_primitives": pprobe.summary(),
         }
         if args.graph:
-            out["graphed"] = {"enabled": step.enabled, "replays": step.replays, "capture_check_max_rel_diff": step.verified,
+            out["graphed"] = {"enabled": step.enabled, "replays": step.replays, "capture_check": step.verified,
                               "disabled_reason": step.disabled_reason}
         if world == 1 and args.model == "adapointr" and args.views == 1 and not args.no_variants and not force_ddp:
             # the other single-GPU configurations of BASELINE.json, so that the driver's record carries them

@@ -234,7 +234,7 @@ class GraphedTrainStep:
         self.enabled = enabled
         self.disabled_reason = None
         self.replays = 0
-        self.verified = None            # None until a capture was compared with the eager step: then the largest difference
+        self.verified = None            # None until a capture was compared with the eager step: then the differences found
         self._seen = {}                 # signature -> eager steps so far
         self._cache = OrderedDict()
         self._with_grad = None
@@ -376,25 +376,36 @@ class GraphedTrainStep:
             if entry is None:
                 return self.step(partial, gt, extra, epoch, denoise_noise)
             if self.verify:
+                opt = self.step.optimizer
+                lr = max(g["lr"] for g in opt.param_groups) or 1.0
                 snap = self._snapshot()
                 torch.cuda.synchronize(device)        # other work + a host synchronisation in front of the replay: the
                 got = self._replay(entry, tensors)    # condition under which an unreliable graph node shows (see above)
+                got_norm = entry["plan"]["norm_coef"][0].clone()
                 after = [p.detach().clone() for p in self.step.params[:8]]
                 torch.cuda.synchronize(device)
                 self._restore(snap)
                 with self._state:
                     want = self.step(partial, gt, extra, epoch, denoise_noise)
-                diff = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in
-                           list(zip(got, want)) + list(zip(after, [p.detach() for p in self.step.params[:8]])))
-                self.verified = diff
-                if not diff <= self.verify_tolerance:
-                    self._disable(f"the replayed step differs from the eager step by {diff:.3e} (relative)")
+                want_norm = opt._plan["norm_coef"][0] if opt._plan is not None else got_norm
+                rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))     # noqa: E731
+                check = {"loss": max(rel(a, b) for a, b in zip(got, want)), "grad_norm": rel(got_norm, want_norm),
+                         "update_mean_over_lr": max(float((a - p.detach()).abs().mean()) / lr
+                                                    for a, p in zip(after, self.step.params[:8]))}
+                self.verified = check
+                bad = [k for k, v in check.items() if not v <= self.verify_tolerance[k]]
+                if bad:
+                    self._disable("the replayed step differs from the eager step: " +
+                                  ", ".join(f"{k} {check[k]:.3e} (limit {self.verify_tolerance[k]:.0e})" for k in bad))
                     return want
             self._cache[key] = entry
             while len(self._cache) > self.max_graphs:
                 self._cache.popitem(last=False)       # drops the graph, its memory pool and its workspaces
             return want if self.verify else self._replay(entry, tensors)
 
-    # relative difference between the replayed and the eager step (losses, first parameters after the update) that the
-    # capture-time check accepts: kernels of this build are deterministic, MIOpen's / in-graph dropout need not be
-    verify_tolerance = 1e-4
+    # What the capture-time check accepts between the replayed and the eager step.  This build's kernels are deterministic
+    # (AdaPoinTr: all three are exactly 0), MIOpen's weight gradients and ATen's scatter-adds are not (float atomics), and
+    # AdamW's early steps turn a rounding-level difference in a near-zero gradient into a full +-lr step of that element:
+    # so the losses (forward) and the gradient norm are compared relatively, the first parameters after the update by the
+    # MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong table or a stale node does)
+    verify_tolerance = {"loss": 1e-4, "grad_norm": 1e-3, "update_mean_over_lr": 2e-2}
