@@ -407,5 +407,7 @@ class GraphedTrainStep:
     # (AdaPoinTr: all three are exactly 0), MIOpen's weight gradients and ATen's scatter-adds are not (float atomics), and
     # AdamW's early steps turn a rounding-level difference in a near-zero gradient into a full +-lr step of that element:
     # so the losses (forward) and the gradient norm are compared relatively, the first parameters after the update by the
-    # MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong table or a stale node does)
-    verify_tolerance = {"loss": 1e-4, "grad_norm": 1e-3, "update_mean_over_lr": 2e-2}
+    # MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong table or a stale node does);
+    # the segmentation variant at bs 16 differs by 1.7e-3 in the gradient norm between two evaluations of one step (GDANet in
+    # train mode: feature-space top-k and hard masks downstream of atomically summed gradients)
+    verify_tolerance = {"loss": 1e-4, "grad_norm": 1e-2, "update_mean_over_lr": 2e-2}
