@@ -378,36 +378,52 @@ class GraphedTrainStep:
             if self.verify:
                 opt = self.step.optimizer
                 lr = max(g["lr"] for g in opt.param_groups) or 1.0
+                rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))     # noqa: E731
+
+                def outcome(losses, norm):
+                    return ([x.detach().clone() for x in losses], norm.detach().clone(),
+                            [p.detach().clone() for p in self.step.params[:8]])
+
+                def distance(a, b):
+                    return {"loss": max(rel(x, y) for x, y in zip(a[0], b[0])), "grad_norm": rel(a[1], b[1]),
+                            "update_mean_over_lr": max(float((x - y).abs().mean()) / lr for x, y in zip(a[2], b[2]))}
+
+                def eager():
+                    with self._state:
+                        losses = self.step(partial, gt, extra, epoch, denoise_noise)
+                    return losses, outcome(losses, opt._plan["norm_coef"][0])
+
                 snap = self._snapshot()
                 torch.cuda.synchronize(device)        # other work + a host synchronisation in front of the replay: the
                 got = self._replay(entry, tensors)    # condition under which an unreliable graph node shows (see above)
-                got_norm = entry["plan"]["norm_coef"][0].clone()
-                after = [p.detach().clone() for p in self.step.params[:8]]
+                replayed = outcome(got, entry["plan"]["norm_coef"][0])
                 torch.cuda.synchronize(device)
                 self._restore(snap)
-                with self._state:
-                    want = self.step(partial, gt, extra, epoch, denoise_noise)
-                want_norm = opt._plan["norm_coef"][0] if opt._plan is not None else got_norm
-                rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))     # noqa: E731
-                check = {"loss": max(rel(a, b) for a, b in zip(got, want)), "grad_norm": rel(got_norm, want_norm),
-                         "update_mean_over_lr": max(float((a - p.detach()).abs().mean()) / lr
-                                                    for a, p in zip(after, self.step.params[:8]))}
-                self.verified = check
-                bad = [k for k, v in check.items() if not v <= self.verify_tolerance[k]]
+                _, first = eager()
+                self._restore(snap)
+                want, second = eager()                # training continues from this one
+                spread, check = distance(first, second), distance(replayed, second)
+                limit = {k: min(max(self.verify_floor[k], 8.0 * spread[k]), self.verify_ceiling[k]) for k in check}
+                self.verified = {"replay_vs_eager": check, "eager_vs_eager": spread}
+                bad = [k for k, v in check.items() if not v <= limit[k]]
                 if bad:
                     self._disable("the replayed step differs from the eager step: " +
-                                  ", ".join(f"{k} {check[k]:.3e} (limit {self.verify_tolerance[k]:.0e})" for k in bad))
+                                  ", ".join(f"{k} {check[k]:.3e} (limit {limit[k]:.1e}, eager vs eager {spread[k]:.1e})"
+                                            for k in bad))
                     return want
             self._cache[key] = entry
             while len(self._cache) > self.max_graphs:
                 self._cache.popitem(last=False)       # drops the graph, its memory pool and its workspaces
             return want if self.verify else self._replay(entry, tensors)
 
-    # What the capture-time check accepts between the replayed and the eager step.  This build's kernels are deterministic
-    # (AdaPoinTr: all three are exactly 0), MIOpen's weight gradients and ATen's scatter-adds are not (float atomics), and
-    # AdamW's early steps turn a rounding-level difference in a near-zero gradient into a full +-lr step of that element:
-    # so the losses (forward) and the gradient norm are compared relatively, the first parameters after the update by the
-    # MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong table or a stale node does);
-    # the segmentation variant at bs 16 differs by 1.7e-3 in the gradient norm between two evaluations of one step (GDANet in
-    # train mode: feature-space top-k and hard masks downstream of atomically summed gradients)
-    verify_tolerance = {"loss": 1e-4, "grad_norm": 1e-2, "update_mean_over_lr": 2e-2}
+    # What the capture-time check accepts between the replayed and the eager step.  The yardstick is measured, not assumed:
+    # the eager step is run TWICE from the snapshot, and the replay may differ from it by 8 x what the two eager runs differ
+    # by, at least `verify_floor`, at most `verify_ceiling`.  This build's kernels are deterministic (AdaPoinTr: every
+    # distance is exactly 0), MIOpen's weight gradients and ATen's scatter-adds are not (float atomics), GDANet's train-mode
+    # forward is not either (feature-space top-k at near-ties: the segmentation variant's loss moves by 2e-4 between two
+    # evaluations at bs 16), and AdamW's early steps turn a rounding-level difference in a near-zero gradient into a full
+    # +-lr step of that element - so losses and the gradient norm are compared relatively and the first parameters after
+    # the update by their MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong
+    # table or a stale graph node does).
+    verify_floor = {"loss": 1e-5, "grad_norm": 1e-4, "update_mean_over_lr": 2e-3}
+    verify_ceiling = {"loss": 1e-2, "grad_norm": 5e-2, "update_mean_over_lr": 5e-2}
