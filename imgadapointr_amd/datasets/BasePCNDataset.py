@@ -26,10 +26,13 @@ def load_image_224(path):
     from PIL import Image
     img = Image.open(path).convert('RGB')
     w, h = img.size
-    if w <= h:
-        img = img.resize((224, max(1, int(round(224 * h / w)))), Image.BILINEAR)
-    else:
-        img = img.resize((max(1, int(round(224 * w / h))), 224), Image.BILINEAR)
+    # torchvision's Resize(224) on a PIL image: shorter side -> 224, longer side -> int(224 * long / short) (truncated),
+    # untouched if the shorter side already is 224
+    if min(w, h) != 224:
+        if w <= h:
+            img = img.resize((224, int(224 * h / w)), Image.BILINEAR)
+        else:
+            img = img.resize((int(224 * w / h), 224), Image.BILINEAR)
     return torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()
 
 
@@ -146,7 +149,7 @@ class PCNv2(BasePCNDataset):
 
 @DATASETS.register_module()
 class ImgPCN(BasePCNDataset):
-    def __init__(self, config, num_imgs_per_obj=6):
+    def __init__(self, config, num_imgs_per_obj=1):       # ImgPCNDataset.py:8 (SegImgPCN samples 6, SegImgPCNDataset.py:18)
         super().__init__(config, include_images=True, num_imgs_per_obj=num_imgs_per_obj)
 
 

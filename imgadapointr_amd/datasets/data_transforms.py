@@ -54,7 +54,9 @@ class RandomMirrorPoints(object):
     def __call__(self, ptcloud, rnd_value):
         sx = -1.0 if rnd_value <= 0.5 else 1.0
         sz = -1.0 if (rnd_value <= 0.25 or 0.5 < rnd_value <= 0.75) else 1.0
-        ptcloud[:, :3] = ptcloud[:, :3] * np.array([sx, 1.0, sz], dtype=ptcloud.dtype)
+        # `+ 0.0`: the reference multiplies by a 3x3 matrix (data_transforms.py:106), whose dot products turn the -0.0 of a
+        # mirrored zero-padding row back into +0.0; everything else is unchanged
+        ptcloud[:, :3] = ptcloud[:, :3] * np.array([sx, 1.0, sz], dtype=ptcloud.dtype) + 0.0
         return ptcloud
 
 

@@ -224,10 +224,13 @@ def run_net(args, config, train_writer=None, val_writer=None):
 
 
 def _synset_names():
-    path = os.path.join('cfgs', 'shapenet_synset_dict.json')
-    if os.path.exists(path):
-        with open(path) as fh:
-            return json.load(fh)
+    """ShapeNet synset id -> category name for the TEST RESULTS table (the reference opens ./cfgs/shapenet_synset_dict.json
+    relative to the working directory, runner.py:428); the copy shipped next to this package serves other directories."""
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for path in (os.path.join('cfgs', 'shapenet_synset_dict.json'), os.path.join(here, 'cfgs', 'shapenet_synset_dict.json')):
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh)
     return {}
 
 

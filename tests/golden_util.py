@@ -162,3 +162,49 @@ def build_demo_tree(root, raws):
                                 raw[:len(raw) - 37 * i])
     with open(os.path.join(root, "PCN.json"), "w") as fh:
         json.dump(cats, fh)
+
+
+def build_demo_images(root, views=24):
+    """24 seeded RGB renders per object of the demo tree in the ImgPCN layout
+    `<subset>/complete/<tax>/<model>/ShapeNetCoreV1/projections/<view>.png`: smooth colour fields (so that resampling
+    matters) of 137 x 137 pixels, every third object 160 x 137 (a non-square image exercises Resize(224)'s aspect rule)."""
+    import os
+    from PIL import Image
+    spec = demo_tree_spec()
+    for ti, tax in enumerate(spec["taxonomies"]):
+        for subset, mid in (("train", "t0"), ("val", "v0"), ("test", "v0")):
+            w, h = (160, 137) if ti % 3 == 2 else (137, 137)
+            d = os.path.join(root, subset, "complete", tax, mid, "ShapeNetCoreV1", "projections")
+            os.makedirs(d, exist_ok=True)
+            yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+            for v in range(views):
+                rng = np.random.default_rng(7000 + 100 * ti + v + (0 if subset == "train" else 50))
+                f = rng.random((3, 3)) * 0.2
+                img = np.stack([127.5 + 127.5 * np.sin(f[c, 0] * xx + f[c, 1] * yy + 6.0 * f[c, 2] + v) for c in range(3)], -1)
+                Image.fromarray(img.astype(np.uint8), "RGB").save(os.path.join(d, f"{v:02d}.png"))
+
+
+def metrics_cases():
+    """Six (taxonomy, model, partial, gt, coarse, dense) validation samples for the Metrics / validate() fixture: ground
+    truth on a sphere shell, predictions = ground truth moved by noise of the F-Score threshold's size (so precision and
+    recall are neither 0 nor 1), one exact prediction, one far-off prediction."""
+    cases = []
+    taxa = ["02691156", "02691156", "03001627", "04379243", "04379243", "04379243"]
+    for i, tax in enumerate(taxa):
+        rng = np.random.default_rng(900 + i)
+        v = rng.standard_normal((2048, 3))
+        gt = (v / np.linalg.norm(v, axis=1, keepdims=True) * (0.3 + 0.02 * i)).astype(np.float32)
+        scale = [0.004, 0.008, 0.0, 0.02, 0.006, 0.1][i]
+        dense = (gt + rng.standard_normal((2048, 3)).astype(np.float32) * np.float32(scale)).astype(np.float32)
+        dense = dense[rng.permutation(2048)]
+        coarse = (gt[:512] + rng.standard_normal((512, 3)).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+        partial = gt[gt[:, 0] > 0][:1024]
+        partial = np.concatenate([partial, np.zeros((2048 - len(partial), 3), np.float32)])
+        cases.append(dict(taxonomy=tax, model=f"m{i}", partial=partial, gt=gt, coarse=coarse, dense=dense))
+    return cases
+
+
+def inference_input(raw):
+    """The demo scan moved by a seeded 1e-3 jitter (float32), the input cloud of the inference fixture."""
+    rng = np.random.default_rng(4242)
+    return (np.asarray(raw, np.float32) + rng.standard_normal(raw.shape).astype(np.float32) * np.float32(1e-3)).astype(np.float32)

@@ -797,3 +797,99 @@ def check_multi_view(device, views=3):
     on_cpu = str(device) == "cpu"
     assert max(d_loss) < (2e-6 if on_cpu else 5e-5) and d_grad < (2e-3 if on_cpu else 3e-2), (d_loss, d_grad)
     return d, d_loss, d_grad
+
+
+def check_validate(device):
+    """`tools.runner.validate` + `Metrics.get` on fixed predictions against the reference's own `validate()` run on the same
+    stub model and loader (tests/golden/metrics_validate.json, generator make_golden_round3.py::metrics_fixture): the four
+    losses, F-Score / CDL1 / CDL2 per sample and per taxonomy, the printed TEST RESULTS table, the returned Metrics object
+    and its ordering rule.  F-Score: the reference thresholds open3d's float64 nearest-neighbour distances, this build the
+    square roots of the Chamfer kernel's float32 squared distances; the fixture counts the distances within 2e-6 of the
+    threshold (3 of 24576), which bounds the possible disagreement."""
+    import re
+    from types import SimpleNamespace
+    from golden_util import metrics_cases
+    from imgadapointr_amd.extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+    from imgadapointr_amd.tools import runner
+    from imgadapointr_amd.utils.config import EasyDict
+    from imgadapointr_amd.utils.metrics import Metrics
+    with open(os.path.join(GOLD, "metrics_validate.json")) as fh:
+        want = json.load(fh)
+    cases = metrics_cases()
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+            self.anchor = torch.nn.Parameter(torch.zeros(1))        # validate() reads the device off the parameters
+
+        def forward(self, partial):
+            c = cases[self.calls]
+            self.calls += 1
+            return t(c["coarse"], device)[None], t(c["dense"], device)[None]
+
+    loader = [((c["taxonomy"],), (c["model"],), (torch.from_numpy(c["partial"])[None], torch.from_numpy(c["gt"])[None]))
+              for c in cases]
+    cfg = EasyDict(dataset=EasyDict(val=EasyDict(_base_=EasyDict(N_POINTS=2048, NAME="PCN"))), consider_metric="CDL1")
+    args = SimpleNamespace(distributed=False, graph_eval=False)
+    lines = []
+    saved = runner.print_log
+    runner.print_log = lambda msg, logger=None: lines.append(str(msg))
+    try:
+        metrics, l1, l2 = runner.validate(Stub().to(device), loader, 3, ChamferDistanceL1(), ChamferDistanceL2(), None, args, cfg)
+    finally:
+        runner.print_log = saved
+    assert Metrics.names() == want["names"] and runner._synset_names() == want["synset_names"]
+    slack = want["distances_within_2e-6_of_the_threshold"] / 2048.0 + 1e-6       # what threshold flips could move an F-Score by
+    got = metrics.state_dict()
+    for k, v in want["metrics"].items():
+        assert abs(got[k] - v) <= (slack if k == "F-Score" else 1e-5 * max(1.0, abs(v))), (k, got[k], v)
+    assert np.allclose(l1, want["loss_L1"], rtol=1e-5, atol=1e-6) and np.allclose(l2, want["loss_L2"], rtol=1e-5, atol=1e-7)
+    for c, ref_vals in zip(cases, want["per_sample"]):
+        vals = [float(v) for v in Metrics.get(t(c["dense"], device)[None], t(c["gt"], device)[None])]
+        assert abs(vals[0] - ref_vals[0]) <= slack and np.allclose(vals[1:], ref_vals[1:], rtol=1e-5, atol=1e-6), (vals, ref_vals)
+    # the log: same lines in the same order; numbers inside them to the printed precision (+ the F-Score slack)
+    number = re.compile(r"-?\d+\.\d+")
+    assert len(lines) == len(want["lines"]), (lines, want["lines"])
+    for a, b in zip(lines, want["lines"]):
+        assert number.sub("#", a) == number.sub("#", b), (a, b)
+        for x, y in zip(number.findall(a), number.findall(b)):
+            assert abs(float(x) - float(y)) <= 1.1e-3 + slack, (a, b)
+    assert [Metrics("CDL1", {"CDL1": 1.0}).better_than(Metrics("CDL1", {"CDL1": 2.0})),
+            Metrics("F-Score", {"F-Score": 0.3}).better_than(Metrics("F-Score", {"F-Score": 0.2})),
+            Metrics("CDL2", {"CDL2": 1.0}).better_than(None)] == want["better_than"]
+    return got
+
+
+def check_inference(device, tmp_path):
+    """`tools/inference.py` as a command line (--pc_root mode, reference inference.py:48-122) on the jittered demo scan
+    against the reference's fine.npy (tests/golden/inference.npz): checkpoint loading through `builder.load_model`, the
+    reader, UpSamplePoints with the same numpy RNG state, the eval forward, the output path.  Query groups (32 points each)
+    are matched by their ranking before comparing, as in `check_eval_forward`."""
+    from golden_util import inference_input, write_ascii_pcd
+    from imgadapointr_amd.tools import inference
+    g = load("inference.npz")
+    raw = load("demo_data.npz")["raw/02691156"]
+    model, _ = build_adapointr("cpu")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = os.path.join(str(tmp_path), "ckpt.pth")
+    torch.save({"base_model": {"module." + k: v for k, v in model.state_dict().items()}}, ckpt)   # a DataParallel checkpoint
+    os.makedirs(os.path.join(str(tmp_path), "in"))
+    write_ascii_pcd(os.path.join(str(tmp_path), "in", "plane.pcd"), inference_input(raw))
+    np.random.seed(77)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        inference.main(["cfgs/PCN_models/AdaPoinTr.yaml", ckpt, "--pc_root", os.path.join(str(tmp_path), "in"),
+                        "--out_pc_root", os.path.join(str(tmp_path), "out"), "--device", str(device)])
+    finally:
+        os.chdir(cwd)
+    fine = np.load(os.path.join(str(tmp_path), "out", "plane", "fine.npy"))
+    want = g["fine"]
+    assert fine.shape == want.shape == (16384, 3) and fine.dtype == np.float32
+    got_g, want_g = fine.reshape(512, 32, 3), want.reshape(512, 32, 3)
+    p = _match_rows(got_g.mean(1), want_g.mean(1))
+    swapped = int((p != np.arange(512)).sum())
+    d = maxdiff(got_g, want_g[p])
+    assert d < 2e-4 and swapped <= 8, (d, swapped)
+    return d, swapped

@@ -221,3 +221,49 @@ def test_readers_and_transforms_match_the_reference_on_the_demo_scans(tmp_path):
                 assert np.array_equal(sha, g[f"{name}/{subset}/{i}/gt_sha1"])
                 n_items += 1
     assert n_items == 32
+
+
+def test_image_datasets_match_the_reference_on_the_demo_tree(tmp_path):
+    """tests/golden/demo_img_data.npz: the reference's ImgPCN / SegImgPCN classes (datasets/ImgPCNDataset.py,
+    SegImgPCNDataset.py over BasePCNDataset.py:36-113) run over the demo tree plus 24 seeded renders per object: which
+    view survives the sampling loop (:72-75 - ImgPCN draws 1 view, SegImgPCN 6 and keeps the last), the PIL load +
+    Resize(224) + ToTensor result bit for bit (square and non-square renders), the class vector, the point branch."""
+    import hashlib
+    import random
+    from golden_util import build_demo_images, build_demo_tree, demo_tree_spec
+    from imgadapointr_amd.datasets import build_dataset_from_cfg
+    from imgadapointr_amd.utils.config import EasyDict
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g, raw = np.load(os.path.join(here, "demo_img_data.npz")), np.load(os.path.join(here, "demo_data.npz"))
+    spec = demo_tree_spec()
+    root = str(tmp_path)
+    build_demo_tree(root, {t: raw[f"raw/{t}"] for t in spec["taxonomies"]})
+    build_demo_images(root)
+    sha = lambda a: np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)   # noqa: E731
+    n_items, shapes = 0, set()
+    for name in ("ImgPCN", "SegImgPCN"):
+        for subset in ("train", "val"):
+            base = EasyDict(NAME=name, CATEGORY_FILE_PATH=os.path.join(root, "PCN.json"), N_POINTS=16384, N_RENDERINGS=8,
+                            CARS=False, PARTIAL_POINTS_PATH=root + "/%s/partial/%s/%s/%02d.pcd",
+                            COMPLETE_POINTS_PATH=root + "/%s/complete/%s/%s/PCN/%s.pcd",
+                            IMG_PATH=root + "/%s/complete/%s/%s/ShapeNetCoreV1/projections/%02d.png")
+            random.seed(spec["seed"] + 1)
+            np.random.seed(spec["seed"] + 1)
+            ds = build_dataset_from_cfg(base, EasyDict(subset=subset))
+            views = [int(os.path.basename(f["img_path"])[:2]) for f in ds.file_list]
+            assert views == g[f"{name}/{subset}/views"].tolist(), (name, subset)
+            assert [str(x) for x in g[f"{name}/{subset}/ids"]] == [f"{f['taxonomy_id']}/{f['model_id']}" for f in ds.file_list]
+            for i in range(len(ds)):
+                tax, mid, item = ds[i]
+                partial, gt, img = item[:3]
+                assert np.array_equal(sha(partial.numpy()), g[f"{name}/{subset}/{i}/partial_sha1"]), (name, subset, i)
+                assert list(img.shape) == g[f"{name}/{subset}/{i}/img_shape"].tolist()
+                assert img.dtype == torch.float32 and np.array_equal(img[:, :8, :8].numpy(), g[f"{name}/{subset}/{i}/img_head"])
+                assert np.array_equal(sha(img.numpy()), g[f"{name}/{subset}/{i}/img_sha1"]), (name, subset, i)
+                shapes.add(tuple(img.shape))
+                if name == "SegImgPCN":
+                    assert np.array_equal(item[3].numpy(), g[f"{name}/{subset}/{i}/cls_vec"])
+                else:
+                    assert len(item) == 3
+                n_items += 1
+    assert n_items == 32 and (3, 224, 224) in shapes and (3, 224, 261) in shapes     # 160 x 137 -> 261 x 224 (truncated)

@@ -220,3 +220,13 @@ def test_batch_size_of_the_image_yaml_under_several_ranks():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_validate_and_metrics_match_the_reference(oracle_backend):
+    import parity_checks as pc
+    print(pc.check_validate("cpu"))
+
+
+def test_inference_cli_matches_the_reference(tmp_path, oracle_backend):
+    import parity_checks as pc
+    print(pc.check_inference("cpu", tmp_path))

@@ -324,3 +324,18 @@ def test_graphed_train_step_equals_eager(native, case):
         lr = 1e-4
         far = sum(int(((pe[n] - pg[n]).abs() > 0.5 * lr).sum()) for n in pe)
         assert far <= 0.02 * sum(p.numel() for p in pe.values()), far
+
+
+@pytest.mark.gpu
+def test_validate_and_metrics_match_the_reference_on_the_hip_path(native):
+    """validate() / Metrics.get on the GPU (Chamfer kernels, fused reductions, device-side F-Score) against the
+    reference's own validate() on the same predictions (tests/golden/metrics_validate.json)."""
+    import parity_checks as pc
+    print(pc.check_validate("cuda"))
+
+
+@pytest.mark.gpu
+def test_inference_cli_matches_the_reference_on_the_hip_path(native, tmp_path):
+    """tools/inference.py end to end on the GPU (graphed eval forward) against the reference's fine.npy."""
+    import parity_checks as pc
+    print(pc.check_inference("cuda", tmp_path))
