@@ -609,9 +609,16 @@ def main():
     probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = not args.graph
     t0 = time.perf_counter()
     last = None
+    marks = []                                  # long runs: one event per 100 steps, for the steady-state picture
     for i in range(args.steps):
+        if args.steps >= 200 and i % 100 == 0:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         last = step(partial, gt, extra)
         aprobe.enabled = pprobe.enabled = gprobe.enabled = False   # ~270 timing events per step cost ~1 ms: only the first timed step carries them
+    if marks:
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[-1].record()
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
@@ -658,6 +665,10 @@ def main():
             "roofline_gemm": gprobe.summary(),
             "roofline_primitives": pprobe.summary(),
         }
+        if marks:
+            n_last = args.steps - 100 * (len(marks) - 2)
+            out["ms_per_step_by_100_steps"] = [round(a.elapsed_time(b) / (100 if i < len(marks) - 2 else n_last), 3)
+                                               for i, (a, b) in enumerate(zip(marks[:-1], marks[1:]))]
         if args.graph:
             out["graphed"] = {"enabled": step.enabled, "replays": step.replays, "capture_check": step.verified,
                               "disabled_reason": step.disabled_reason}

@@ -3,7 +3,7 @@
 Starts `python bench.py --steps N --no-cpu-baseline` as a child process and polls `rocm-smi` (average socket power,
 sclk / mclk) every ~0.25 s; prints the idle reading, the readings during the timed region and the board's power cap.
 
-    python benchmarks/power_trace.py [steps]
+    python benchmarks/power_trace.py [steps] [file for the bench's JSON line]
 """
 import json
 import os
@@ -33,10 +33,11 @@ def reading():
 
 def main():
     steps = sys.argv[1] if len(sys.argv) > 1 else "300"
+    json_out = sys.argv[2] if len(sys.argv) > 2 else None          # where the bench's full JSON line goes
     print("power cap:", json.dumps(smi("--showmaxpower")))
     print("idle:", reading())
     child = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "10",
-                              "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                              "--no-cpu-baseline", "--no-variants"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     t0 = time.time()
     rows = []
     while child.poll() is None:
@@ -44,6 +45,11 @@ def main():
         time.sleep(0.25)
     out = child.stdout.read().strip().splitlines()
     print(out[-1][:400] if out else "no bench output")
+    if out and json_out:
+        with open(json_out, "w") as fh:
+            fh.write(out[-1] + "\n")
+        d = json.loads(out[-1])
+        print("ms per step, by 100 steps:", d.get("ms_per_step_by_100_steps"))
     for t, p, s, m in rows:
         print(f"  t={t:6.2f} s  power {p}  sclk {s}  mclk {m}")
 
