@@ -105,7 +105,8 @@ class ChamferProbe:
         # HBM traffic and pipe activity of this launch come from separate rocprofv3 --pmc passes of the same kernel
         # (cannot be collected from inside the timed run); their summary is committed.
         pmc_name = "chamfer_mfma_pmc.json" if on_mfma else "chamfer_pmc.json"
-        pmc_file = os.path.join(ROOT, "profiles", "round2" if on_mfma else "round1", pmc_name)
+        pmc_round = "round4" if on_mfma else "round1"      # the MFMA search was re-profiled on the round-4 kernel
+        pmc_file = os.path.join(ROOT, "profiles", pmc_round, pmc_name)
         traffic, pmc = None, {}
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
@@ -115,7 +116,7 @@ class ChamferProbe:
             "kernel": "Chamfer 16384x16384 forward launch (exact nearest neighbours, both directions; per direction the "
                       "adaptive policy ran: " + " / ".join(names[a] for a in algos) + ")",
             "launches": len(ms), "avg_launch_ms": round(avg_ms, 4), "traffic": traffic,
-            "traffic_source": f"profiles/{'round2' if on_mfma else 'round1'}/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+            "traffic_source": f"profiles/{pmc_round}/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
             "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic": {"achieved": round(alg_flops / (avg_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                             "note": "8 FLOP per pair (3 sub, 3 mul, 2 add), every pair of both directions"},
@@ -339,7 +340,8 @@ class PrimitiveProbe:
                 continue
             # HBM traffic and pipe activity: separate rocprofv3 --pmc passes over the same launches
             # (benchmarks/primitives_only.py, benchmarks/pmc_passes.sh), averages per launch
-            pmc_file = os.path.join(ROOT, "profiles", "round3", f"{kind}_pmc.json")
+            pmc_dir = "round4" if kind == "fps" else "round3"          # FPS was re-profiled on the round-4 kernel
+            pmc_file = os.path.join(ROOT, "profiles", pmc_dir, f"{kind}_pmc.json")
             pmc = {}
             if os.path.exists(pmc_file):
                 with open(pmc_file) as fh:
@@ -353,7 +355,7 @@ class PrimitiveProbe:
                          "hbm": {"achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(gbs / PEAK_HBM_GBS, 5), "algorithmic_bytes_per_step": nbytes},
                          "traffic": (round(pmc["hbm_traffic_bytes"] * len(recs)) if "hbm_traffic_bytes" in pmc else None),
-                         "traffic_source": f"profiles/round3/{kind}_pmc.json (per-launch average x launches; FETCH_SIZE x 2 "
+                         "traffic_source": f"profiles/{pmc_dir}/{kind}_pmc.json (per-launch average x launches; FETCH_SIZE x 2 "
                                            "upper bound + WRITE_SIZE)",
                          "pmc": {k: round(pmc[k], 4) for k in ("valu_busy_fraction", "salu_busy_fraction",
                                                                "waves_resident_per_simd", "sq_wait_any_share_of_wave_cycles",
