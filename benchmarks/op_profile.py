@@ -1,6 +1,6 @@
 """aten-level view of one train step (which ops own the element-wise / copy / reduce kernels).
 
-    python benchmarks/op_profile.py > gpurun_out/op_profile.txt
+    python benchmarks/op_profile.py [adapointr|img|seg] > gpurun_out/op_profile.txt
 """
 import os
 import sys
@@ -20,13 +20,11 @@ def main():
     device = torch.device("cuda", 0)
     _native.load()
     enable_tuned_gemm()
-    cfg = bench.load_cfg()
-    torch.manual_seed(0)
-    model = build_model_from_cfg(cfg.model).to(device)
-    model.train()
-    step = TrainStep(model, builder.build_optimizer(model, cfg), getattr(cfg, "grad_norm_clip", 10), 1)
-    partial = (torch.rand(bench.BATCH, bench.N_PARTIAL, 3) - 0.5).to(device)
-    gt = (torch.rand(bench.BATCH, bench.N_GT, 3) - 0.5).to(device)
+    which = sys.argv[1] if len(sys.argv) > 1 else "adapointr"          # adapointr | img | seg
+    model, cfg, spec, _step, (partial, gt, extra), B = bench.make_workload(which, device)
+
+    def step(p, g):
+        return _step(p, g, extra)
     for _ in range(5):
         step(partial, gt)
     torch.cuda.synchronize()

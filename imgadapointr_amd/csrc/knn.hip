@@ -27,19 +27,18 @@ constexpr int kWaves = kTPB / 64;
 // queries (the 64-seed denoise search over 16384 points) 4 — one per wave — fill the chip instead.
 constexpr int kMaxK = 64;
 
+// min over the wave (all lanes receive it).  Written as ISA: the compiler lowers fminf(v, update_dpp(v)) to v_mov_b32 +
+// v_mov_b32_dpp + a canonicalising v_max + v_min (five instructions and a nop per step); `v_min_f32_dpp` does a step in
+// one instruction.  Every extraction round of a query starts with this chain (up to 2 k of them per query), so it is
+// most of a query's serial latency.  A lane whose source lane does not exist keeps its value; a DPP read of a VGPR
+// written by the previous VALU instruction needs two wait states (s_nop 1), which the assembler does not add inside an
+// asm block.  v_min_f32 returns the other operand for a quiet NaN, as fminf does (NaN coordinates are never selected).
 __device__ __forceinline__ float wave_min_f32(float v) {
-  float t;
-#define PTOPS_DPP_STEP(ctrl, rmask)                                                            \
-  t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),        \
-                                                            __builtin_bit_cast(int, v), ctrl,  \
-                                                            rmask, 0xf, false));               \
-  v = fminf(v, t);
-  PTOPS_DPP_STEP(0x111, 0xf)
-  PTOPS_DPP_STEP(0x112, 0xf)
-  PTOPS_DPP_STEP(0x114, 0xf)
-  PTOPS_DPP_STEP(0x118, 0xf)
-  PTOPS_DPP_STEP(0x142, 0xa)
-  PTOPS_DPP_STEP(0x143, 0xc)
+#define PTOPS_DPP_STEP(ctrl) "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t"
+  asm volatile(PTOPS_DPP_STEP("row_shr:1 row_mask:0xf") PTOPS_DPP_STEP("row_shr:2 row_mask:0xf")
+               PTOPS_DPP_STEP("row_shr:4 row_mask:0xf") PTOPS_DPP_STEP("row_shr:8 row_mask:0xf")
+               PTOPS_DPP_STEP("row_bcast:15 row_mask:0xa") PTOPS_DPP_STEP("row_bcast:31 row_mask:0xc") "s_nop 1"
+               : "+v"(v));
 #undef PTOPS_DPP_STEP
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
@@ -249,13 +248,18 @@ PTOPS_API int ptops_knn(const float* xyz, const float* new_xyz, int B, int N, in
   if (B == 0 || S == 0) return PTOPS_OK;
   PTOPS_REQUIRE(xyz && new_xyz && idx, "knn: null pointer");
   PTOPS_REQUIRE(B <= 65535, "knn: B=%d exceeds grid.y limit", B);
+  // queries per workgroup: every workgroup of a cloud stages the same candidate tiles (through L2: 81 MB counted against
+  // 19 MB algorithmic on the 2048 x 2048 call, profiles/round3/knn_pmc.json), so launches with enough queries to fill the
+  // chip anyway (>= 4 workgroups per CU at 32 per workgroup) take 32 per workgroup and stage half as often
   const bool few = (long long)B * S < 16384;
-  const int qpb = few ? 4 : 16;
+  const bool many = (long long)B * S >= 32768;
+  const int qpb = few ? 4 : (many ? 32 : 16);
   dim3 grid(ptops::ceil_div(S, qpb), B), block(kTPB);
-#define PTOPS_KNN_LAUNCH(P)                                                                             \
-  do {                                                                                                  \
-    if (few) hipLaunchKernelGGL((knn_kernel<P, 4>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx); \
-    else hipLaunchKernelGGL((knn_kernel<P, 16>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);    \
+#define PTOPS_KNN_LAUNCH(P)                                                                              \
+  do {                                                                                                   \
+    if (few) hipLaunchKernelGGL((knn_kernel<P, 4>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);  \
+    else if (many) hipLaunchKernelGGL((knn_kernel<P, 32>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx); \
+    else hipLaunchKernelGGL((knn_kernel<P, 16>), grid, block, 0, stream, xyz, new_xyz, N, S, k, idx);     \
   } while (0)
   if (N <= 256) PTOPS_KNN_LAUNCH(4);
   else if (N <= 512) PTOPS_KNN_LAUNCH(8);
