@@ -192,8 +192,8 @@ class AttentionProbe:
                "note": "achieved = fp32 product FLOPs of the launches (forward 2 GEMMs, dq + dk/dv pair 7, single-pass "
                        "backward 5) per second; executed = x 6 for launches on the bf16 matrix pipe (three-piece split, six "
                        "piece products per fp32 product), x 1 for the f32-MFMA kernels; frac = executed / dense bf16 peak. "
-                       "pmc = separate rocprofv3 --pmc passes of the same kernels (profiles/round2/attention_split3_pmc.json)"}
-        pmc_file = os.path.join(ROOT, "profiles", "round2", "attention_split3_pmc.json")
+                       "pmc = separate rocprofv3 --pmc passes of the same kernels as they are now (profiles/round4/attention_pmc.json)"}
+        pmc_file = os.path.join(ROOT, "profiles", "round4", "attention_pmc.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 out["pmc"] = [{"kernel": k["kernel"], "workgroups": k["grid_threads"] // k["workgroup"],
@@ -340,7 +340,7 @@ class PrimitiveProbe:
                 continue
             # HBM traffic and pipe activity: separate rocprofv3 --pmc passes over the same launches
             # (benchmarks/primitives_only.py, benchmarks/pmc_passes.sh), averages per launch
-            pmc_dir = "round4" if kind == "fps" else "round3"          # FPS was re-profiled on the round-4 kernel
+            pmc_dir = "round4"                                         # both were re-profiled on the round-4 kernels
             pmc_file = os.path.join(ROOT, "profiles", pmc_dir, f"{kind}_pmc.json")
             pmc = {}
             if os.path.exists(pmc_file):
