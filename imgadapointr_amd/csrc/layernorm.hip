@@ -19,10 +19,20 @@ namespace {
 
 constexpr int kWaves = 4;
 
+// Sum over the wave (all lanes receive it).  `__shfl_xor` compiles to ds_bpermute_b32, an LDS round trip per step: six
+// dependent ones per reduction and two or three dependent reductions per row made the row latency, not HBM, the bound
+// (3.6 TB/s forward).  Here: an inclusive DPP scan written as ISA (row_shr 1, 2, 4, 8 inside each row of 16, row_bcast:15
+// into rows 1 and 3, row_bcast:31 into rows 2 and 3; one v_add_f32_dpp per step; a lane whose source does not exist keeps
+// its value), lane 63 holds the total.  The assembler adds no wait states inside an asm block: a DPP read of a VGPR
+// written by the previous VALU instruction needs two (s_nop 1).  A fixed order, so results stay run-to-run identical.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+#define PTOPS_DPP_STEP(ctrl) "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t"
+  asm volatile(PTOPS_DPP_STEP("row_shr:1 row_mask:0xf") PTOPS_DPP_STEP("row_shr:2 row_mask:0xf")
+               PTOPS_DPP_STEP("row_shr:4 row_mask:0xf") PTOPS_DPP_STEP("row_shr:8 row_mask:0xf")
+               PTOPS_DPP_STEP("row_bcast:15 row_mask:0xa") PTOPS_DPP_STEP("row_bcast:31 row_mask:0xc") "s_nop 1"
+               : "+v"(v));
+#undef PTOPS_DPP_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
