@@ -1,7 +1,7 @@
 """fp32 GEMM on the bf16 matrix pipe (csrc/gemm_split3.hip) against torch's fp32 GEMM (hipBLASLt / rocBLAS with the shipped
 per-shape selections): error of both against float64, and time, on the dense-layer shapes of the bs = 32 train step.
 
-    python benchmarks/gemm_split3_probe.py > gpurun_out/gemm_split3_probe.log
+    python benchmarks/gemm_split3_probe.py [rows,rows,...] > gpurun_out/gemm_split3_probe.log
 """
 import os
 import sys
@@ -31,7 +31,12 @@ def main():
     print(enable_tuned_gemm(), flush=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    shapes = [(18432, 384, 384), (18432, 1152, 384), (18432, 768, 384), (18432, 384, 768), (18432, 1024, 384),
+    if len(sys.argv) > 1:          # row counts given: the layer widths of the step at those rows (e.g. 9216,4096 = bs 16)
+        shapes = [(int(m), n, k) for m in sys.argv[1].split(",")
+                  for n, k in ((384, 384), (1152, 384), (768, 384), (384, 768), (1024, 384), (1024, 1024), (384, 1024), (512, 384))]
+    else:
+        shapes = None
+    shapes = shapes or [(18432, 384, 384), (18432, 1152, 384), (18432, 768, 384), (18432, 384, 768), (18432, 1024, 384),
               (18432, 1024, 1024), (18432, 384, 1024), (8192, 384, 384), (8192, 1152, 384), (8192, 768, 384),
               (8192, 384, 768), (16384, 512, 512), (65536, 512, 512), (18432, 512, 768)]
     print(f"{'M':>6} {'N':>5} {'K':>5} | fwd x.W^T: torch us  split3 us  speedup | dgrad dy.W: torch  split3  speedup | "

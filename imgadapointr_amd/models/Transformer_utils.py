@@ -117,16 +117,22 @@ def _split3_ok(a, k):
 
 
 def _use_split3_forward(x2, weight):
+    """Where x.W^T on the split-bf16 kernel beats the library's fp32 MFMA kernels (benchmarks/gemm_split3_probe.py;
+    profiles/round4/gemm_split3_probe_bs16_v1.log for the rows of the batch-16 variants): every width from 8192 rows up
+    (1.03-1.7x at 8192 / 9216 rows, 1.1-1.4x at 18432), wide outputs from 4096 rows up (1.2x at N = 1024; narrower ones
+    tie or lose there: 0.64x at N = 384, K = 768)."""
     M, K = x2.shape
     N = weight.size(0)
-    return (_split3_ok(x2, K) and _split3_ok(weight, K) and N >= 128 and (M >= 16384 or (M >= 8192 and N >= 768)))
+    return (_split3_ok(x2, K) and _split3_ok(weight, K) and N >= 128 and (M >= 8192 or (M >= 4096 and N >= 1024)))
 
 
 def _use_split3_dgrad(g2, weight):
     M, N = g2.shape                     # contraction over N (out_features), output width K (in_features)
     K = weight.size(1)
+    # the k-strided operand form loses to the library below 16384 rows except on the 1024-wide squares (1.1-1.2x at 8192 /
+    # 9216 rows; 0.5-0.97x elsewhere: profiles/round4/gemm_split3_probe_bs16_v1.log)
     return (_split3_ok(g2, N) and weight.is_cuda and weight.dtype == torch.float32 and weight.stride(1) == 1
-            and K >= 128 and M >= 16384 and (N >= 512 or K >= 1024))
+            and K >= 128 and ((M >= 16384 and (N >= 512 or K >= 1024)) or (M >= 8192 and N >= 1024 and K >= 1024)))
 
 
 USE_SPLIT3_WGRAD = os.environ.get("PTOPS_SPLIT3_WGRAD", "1") != "0"
