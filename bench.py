@@ -531,9 +531,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="clouds (objects) per GPU; default 32 for adapointr, 16 for img / seg (BASELINE.json configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the train step from a HIP graph (GraphedTrainStep; one process, no data-parallel wrapper). "
-                         "The per-kernel roofline probes are Python-side and see nothing of a replay, so they are off")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the train step from a HIP graph (GraphedTrainStep; one process, no data-parallel wrapper); "
+                         "auto = on for one process, off under torch.distributed.  The per-kernel roofline probes are "
+                         "Python-side and see nothing of a replay: the FIRST timed step runs eagerly and carries them")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` block (configs[2] / [4] at bs 16, eager and graphed, 10 timed steps each) that "
                          "the default one-GPU run appends after the headline region")
@@ -577,11 +578,15 @@ def main():
     model, cfg, spec, step, (partial, gt, extra), B = make_workload(args.model, device, args.batch, args.views, rank, wrap)
     args.batch = B
     samples = B * args.views
-    if args.graph:
+    if args.graph == "auto":
+        # one process, no data-parallel wrapper: the step is replayed from a HIP graph (utils/graph_runner.py; it falls back
+        # to eager by itself when the capture-time check fails).  N > 1 stays eager: the bucket hooks launch RCCL from Python.
+        args.graph = "on" if (wrap is None and world == 1) else "off"
+    eager_step = step
+    if args.graph == "on":
         if wrap is not None:
-            raise SystemExit("--graph: the data-parallel wrapper launches collectives from Python hooks; one process only")
+            raise SystemExit("--graph on: the data-parallel wrapper launches collectives from Python hooks; one process only")
         step = GraphedTrainStep(step, warmup=3, verify=True)
-        args.warmup = max(args.warmup, 3 + 1 + 1)
 
     probe = ChamferProbe(N_GT, N_GT)
     _native.chamfer_forward = probe
@@ -601,14 +606,21 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
     note("model built; warm-up")
+    graph_warmup = 0
     for i in range(args.warmup):
-        step(partial, gt, extra)
+        eager_step(partial, gt, extra)
         if i == 0:
             torch.cuda.synchronize()
             note("first step done")
+    if args.graph == "on":           # untimed: three eager steps in the graph's own workspaces, capture + check, one replay
+        while graph_warmup < 8 and step.enabled and step.replays < 1:
+            step(partial, gt, extra)
+            graph_warmup += 1
+        note(f"graphed step: enabled={step.enabled} after {graph_warmup} more untimed steps, capture check {step.verified}")
     barrier()
     note("timed region")
-    probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = not args.graph
+    probe.enabled = aprobe.enabled = pprobe.enabled = gprobe.enabled = True
+    graphed = args.graph == "on" and step.enabled
     t0 = time.perf_counter()
     last = None
     marks = []                                  # long runs: one event per 100 steps, for the steady-state picture
@@ -616,7 +628,8 @@ def main():
         if args.steps >= 200 and i % 100 == 0:
             marks.append(torch.cuda.Event(enable_timing=True))
             marks[-1].record()
-        last = step(partial, gt, extra)
+        # the first timed step is always an eager one: it carries the per-kernel events (a replay runs no Python)
+        last = (eager_step if (i == 0 or not graphed) else step)(partial, gt, extra)
         aprobe.enabled = pprobe.enabled = gprobe.enabled = False   # ~270 timing events per step cost ~1 ms: only the first timed step carries them
     if marks:
         marks.append(torch.cuda.Event(enable_timing=True))
@@ -671,12 +684,15 @@ def main():
             n_last = args.steps - 100 * (len(marks) - 2)
             out["ms_per_step_by_100_steps"] = [round(a.elapsed_time(b) / (100 if i < len(marks) - 2 else n_last), 3)
                                                for i, (a, b) in enumerate(zip(marks[:-1], marks[1:]))]
-        if args.graph:
-            out["graphed"] = {"enabled": step.enabled, "replays": step.replays, "capture_check": step.verified,
-                              "disabled_reason": step.disabled_reason}
+        out["graphed"] = ({"enabled": step.enabled, "replays": step.replays, "capture_check": step.verified,
+                           "disabled_reason": step.disabled_reason, "untimed_graph_warmup_steps": graph_warmup,
+                           "note": "timed steps 2..K are replays of one HIP graph of the whole step "
+                                   "(utils/graph_runner.py::GraphedTrainStep); timed step 1 runs eagerly and carries the "
+                                   "per-kernel events of the roofline entries"}
+                          if args.graph == "on" else {"enabled": False})
         if world == 1 and args.model == "adapointr" and args.views == 1 and not args.no_variants and not force_ddp:
             # the other single-GPU configurations of BASELINE.json, so that the driver's record carries them
-            del step, model
+            del step, eager_step, model
             torch.cuda.empty_cache()
             out["variants"] = {w: run_variant(w, device, note=note) for w in ("img", "seg", "adapointr")}
             out["variants"]["note"] = ("10 timed steps each after the headline region, one process: eager TrainStep, then the same "

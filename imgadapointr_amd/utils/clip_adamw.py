@@ -15,7 +15,7 @@ _ROW = 64      # bytes per tensor row of the device table (ptops_adamw_row_bytes
 
 class ClipAdamW(torch.optim.AdamW):
     def __init__(self, params, **kwargs):
-        self._plan = None                      # before super().__init__: it calls add_param_group
+        self._plan = self._eager_plan = None    # before super().__init__: it calls add_param_group
         self._ring = 0
         params = list(params)
         flat = [p for g in params for p in g["params"]] if params and isinstance(params[0], dict) else params
@@ -28,8 +28,15 @@ class ClipAdamW(torch.optim.AdamW):
     def _sync_steps(self):
         """Write the plan's step counts back into state[p]["step"] (torch's format) before anyone else reads them."""
         if getattr(self, "_plan", None) is not None:
-            for p, n in zip(self._plan["params"], self._plan["steps"]):
-                self.state[p]["step"].fill_(float(n))
+            steps = self._plan["steps"]
+            tensors = [self.state[p]["step"] for p in self._plan["params"]]
+            if len(tensors) > 8 and float(steps.min()) == float(steps.max()) and all(t.is_cuda for t in tensors):
+                # the usual case (every parameter stepped every time): two multi-tensor launches instead of one per tensor
+                torch._foreach_zero_(tensors)
+                torch._foreach_add_(tensors, float(steps[0]))
+            else:
+                for t, n in zip(tensors, steps):
+                    t.fill_(float(n))
 
     def state_dict(self):
         self._sync_steps()
@@ -42,7 +49,7 @@ class ClipAdamW(torch.optim.AdamW):
 
     # the plan caches the addresses of the moment tensors: anything that may replace them drops it
     def load_state_dict(self, state_dict):
-        self._plan = None
+        self._plan = self._eager_plan = None
         return super().load_state_dict(state_dict)
 
     def add_param_group(self, param_group):
@@ -190,8 +197,13 @@ class ClipAdamW(torch.optim.AdamW):
                 self._plan = None
                 return self._stock(max_norm)
         if stale or any(self.state[p]["exp_avg"].data_ptr() != int(a) for p, a in zip(params[:4], self._plan["rows"][:4, 2])):
-            self._sync_steps()                        # the old plan's counters go back into the state first
-            self._plan = self._make_plan(params, group_of)
+            kept = getattr(self, "_eager_plan", None)
+            if (kept is not None and kept["key"] == key
+                    and all(self.state[p]["exp_avg"].data_ptr() == int(a) for p, a in zip(params[:4], kept["rows"][:4, 2]))):
+                self._activate(kept)                  # eager and graphed steps alternating: the eager plan is still good
+            else:
+                self._sync_steps()                    # the old plan's counters go back into the state first
+                self._plan = self._eager_plan = self._make_plan(params, group_of)
         plan = self._plan
         self._pre_hooks()
         plan["rows"][:, 1] = [p.grad.data_ptr() for p in params]
