@@ -533,7 +533,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the train step from a HIP graph (GraphedTrainStep; one process, no data-parallel wrapper); "
-                         "auto = on for one process, off under torch.distributed.  The per-kernel roofline probes are "
+                         "auto = on for --model img | seg in one process, off for the device-bound headline step and under "
+                         "torch.distributed.  The per-kernel roofline probes are "
                          "Python-side and see nothing of a replay: the FIRST timed step runs eagerly and carries them")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` block (configs[2] / [4] at bs 16, eager and graphed, 10 timed steps each) that "
@@ -579,9 +580,12 @@ def main():
     args.batch = B
     samples = B * args.views
     if args.graph == "auto":
-        # one process, no data-parallel wrapper: the step is replayed from a HIP graph (utils/graph_runner.py; it falls back
-        # to eager by itself when the capture-time check fails).  N > 1 stays eager: the bucket hooks launch RCCL from Python.
-        args.graph = "on" if (wrap is None and world == 1) else "off"
+        # The batch-16 image / segmentation steps are bound by the host's launch rate and are replayed from a HIP graph
+        # (utils/graph_runner.py; falls back to eager by itself when its capture-time check fails).  The headline bs-32 step
+        # is device-bound: measured per step with events on one box, replays 30.1 ms vs 30.05 eager, and the eager step that
+        # has to carry the per-kernel events costs the graphed run 12 ms of transients (profiles/round4/README.md) - it stays
+        # eager.  N > 1 stays eager as well: the bucket hooks launch RCCL from Python.
+        args.graph = "on" if (wrap is None and world == 1 and args.model != "adapointr") else "off"
     eager_step = step
     if args.graph == "on":
         if wrap is not None:
@@ -624,7 +628,12 @@ def main():
     t0 = time.perf_counter()
     last = None
     marks = []                                  # long runs: one event per 100 steps, for the steady-state picture
+    per_step = os.environ.get("PTOPS_BENCH_STEP_EVENTS") == "1"      # diagnostics: one event per step
+    step_marks = []
     for i in range(args.steps):
+        if per_step:
+            step_marks.append(torch.cuda.Event(enable_timing=True))
+            step_marks[-1].record()
         if args.steps >= 200 and i % 100 == 0:
             marks.append(torch.cuda.Event(enable_timing=True))
             marks[-1].record()
@@ -634,7 +643,12 @@ def main():
     if marks:
         marks.append(torch.cuda.Event(enable_timing=True))
         marks[-1].record()
+    if per_step:
+        step_marks.append(torch.cuda.Event(enable_timing=True))
+        step_marks[-1].record()
     barrier()
+    if per_step:
+        note("ms per timed step: " + " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(step_marks[:-1], step_marks[1:])))
     dt = time.perf_counter() - t0
     note(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     probe.enabled = aprobe.enabled = False
