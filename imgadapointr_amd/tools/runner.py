@@ -25,7 +25,7 @@ from .. import _native
 from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from ..utils.AverageMeter import AverageMeter
 from ..utils.flat_ddp import FlatDDP
-from ..utils.graph_runner import GraphedForward
+from ..utils.graph_runner import GraphedForward, GraphedTrainStep
 from ..utils.logger import get_logger, print_log
 from ..utils.metrics import Metrics
 from . import builder
@@ -162,6 +162,12 @@ def run_net(args, config, train_writer=None, val_writer=None):
     scheduler = builder.build_scheduler(base_model, optimizer, config, last_epoch=start_epoch - 1)
     step = TrainStep(base_model, optimizer, getattr(config, 'grad_norm_clip', 10),
                      getattr(config, 'step_per_update', 1))
+    if getattr(args, 'graph_train', False) and not args.distributed and device.type == 'cuda':
+        # --graph_train: the whole step replayed from one HIP graph per (input shapes, epoch-dependent scalars); pays for
+        # the launch-bound batch-16 image / segmentation models (utils/graph_runner.py); eager again by itself if its
+        # capture-time check against the eager step fails
+        step = GraphedTrainStep(step)
+        print_log('Train steps are replayed from HIP graphs (--graph_train)', logger=logger)
     log_every = int(getattr(args, 'log_every', 100))
 
     for epoch in range(start_epoch, config.max_epoch + 1):

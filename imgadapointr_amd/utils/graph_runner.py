@@ -211,7 +211,9 @@ class GraphedTrainStep:
       * the optimizer's per-step scalars (lr, weight decay, bias corrections, step count) -> they live in ClipAdamW's
         device table, rewritten by an ordinary stream-ordered copy before each replay (`graph_before_replay`); the
         gradients sit at fixed addresses of the graph's memory pool;
-      * the epoch-dependent coarse-loss weight of the VariableLoss models -> part of the cache key (one capture per value);
+      * Python-side numbers that become kernel arguments - the epoch-dependent coarse-loss weight of the VariableLoss
+        models, the BatchNorm momenta the runner's scheduler changes between epochs -> part of the cache key (one capture
+        per combination of values);
       * the denoise jitter -> drawn eagerly before the replay with exactly the call the model would make (same generator
         consumption as the eager step), handed in as a static input; other RNG consumers (GDANet's dropout) use torch's
         graph-safe generator state;
@@ -238,6 +240,7 @@ class GraphedTrainStep:
         self._seen = {}                 # signature -> eager steps so far
         self._cache = OrderedDict()
         self._with_grad = None
+        self._bn = None
 
     # delegate what the runner touches on a TrainStep
     @property
@@ -247,6 +250,21 @@ class GraphedTrainStep:
     @property
     def model(self):
         return self.step.model
+
+    @property
+    def ddp(self):
+        return self.step.ddp
+
+    def _host_scalars(self, epoch):
+        """Python-side numbers that end up as kernel arguments of the captured launches: a graph is only valid for the
+        values it was captured with, so they are part of its cache key.  The epoch-dependent coarse-loss weight of the
+        VariableLoss models (get_loss) and the BatchNorm momenta, which the runner's BN-momentum scheduler changes between
+        epochs (utils/misc.py::build_lambda_bnsche)."""
+        if self._bn is None:
+            self._bn = [m for m in self.step.net.modules()
+                        if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm,)) and m.momentum is not None]
+        weight = getattr(self.step.net, "coarse_loss_weight", lambda e: 1.0)(epoch)
+        return (float(weight),) + tuple(float(m.momentum) for m in self._bn)
 
     def zero_grad(self):
         self.step.zero_grad()
@@ -348,8 +366,7 @@ class GraphedTrainStep:
             has_noise = denoise_noise is not None
             if has_noise:
                 tensors = tensors + [denoise_noise]
-            weight = getattr(self.step.net, "coarse_loss_weight", lambda e: 1.0)(epoch)
-            key = (signature(tensors), float(weight), len(extra), has_noise)
+            key = (signature(tensors), self._host_scalars(epoch), len(extra), has_noise)
             entry = self._cache.get(key)
             if entry is not None:
                 self._cache.move_to_end(key)

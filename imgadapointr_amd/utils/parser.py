@@ -19,6 +19,8 @@ def build_parser():
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none', help='job launcher')
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--num_workers', type=int, default=4)
+    p.add_argument('--graph_train', action='store_true', default=False,
+                   help='replay the train step from HIP graphs (one process; for the launch-bound batch-16 models)')
     p.add_argument('--total_bs', type=int, default=None,
                    help='batch over all ranks; overrides the YAML (the reference ignores its YAML in distributed mode)')
     p.add_argument('--seed', type=int, default=0, help='random seed')

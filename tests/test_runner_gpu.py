@@ -45,6 +45,22 @@ def test_run_net_full_model_on_gpu(tmp_path, native):
     best2 = runner.run_net(args, cfg)
     assert isinstance(best2, Metrics)
     assert torch.load(tmp_path / "ckpt-last.pth", weights_only=False)["epoch"] == 1
+    # --graph_train: one more epoch of six iterations (three eager, one captured + checked, two replays) through HIP graphs
+    from imgadapointr_amd.utils import graph_runner
+    made = []
+    orig = graph_runner.GraphedTrainStep.__init__
+    graph_runner.GraphedTrainStep.__init__ = lambda self, *a, **k: (orig(self, *a, **k), made.append(self))[0]
+    try:
+        cfg.dataset.train._base_.LENGTH = 12
+        cfg.max_epoch = 2
+        args.graph_train = True
+        best3 = runner.run_net(args, cfg)
+    finally:
+        graph_runner.GraphedTrainStep.__init__ = orig
+    assert isinstance(best3, Metrics) and all(v == v for v in best3.state_dict().values())
+    assert len(made) == 1 and made[0].enabled and made[0].replays >= 2, (made[0].disabled_reason, made[0].replays)
+    ck = torch.load(tmp_path / "ckpt-last.pth", weights_only=False)
+    assert ck["epoch"] == 2 and {float(s["step"]) for s in ck["optimizer"]["state"].values()} == {2.0 + 2.0 + 6.0}
 
 
 @pytest.mark.gpu
