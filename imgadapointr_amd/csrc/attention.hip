@@ -245,6 +245,19 @@ __device__ __forceinline__ void xcd_job(int remap, int& bx, int& bh) {
 // the six piece products, smallest first: (piece of A, piece of B)
 #define PTOPS_SPLIT3_TERMS(F) F(2, 0) F(1, 1) F(0, 2) F(1, 0) F(0, 1) F(0, 0)
 
+// ABL != 0: timing experiments only (benchmarks/attention_ablation.py; results are WRONG): bit 0 = K / V staged with one
+// conversion per pair instead of the three-piece split, bit 1 = P likewise, bit 2 = no softmax arithmetic, bit 3 = no
+// S^T MFMAs, bit 4 = no O^T MFMAs, bit 5 = tiles after the first neither loaded nor staged.
+__device__ __forceinline__ Pieces3 cheap8(const float (&x)[8]) {
+  bf16x8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (__bf16)x[i];
+  Pieces3 p;
+  p.h = p.m = p.l = __builtin_bit_cast(uint4, h);
+  return p;
+}
+
+template <int ABL>
 __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
   constexpr int W = 4;
   constexpr int kKRow = 33;                                  // padded: conflict-free ds_write_b128 of 8 lanes per key
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
     }
   };
   auto store_tile = [&](int buf) {
-    const Pieces3 pk = split8(kx), pv = split8(vx);
+    const Pieces3 pk = (ABL & 1) ? cheap8(kx) : split8(kx), pv = (ABL & 1) ? cheap8(vx) : split8(vx);
     sK[buf][0 * 8 + k_slot][k_row] = pk.h;
     sK[buf][1 * 8 + k_slot][k_row] = pk.m;
     sK[buf][2 * 8 + k_slot][k_row] = pk.l;
@@ -321,8 +334,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    const int buf = (ABL & 32) ? 0 : (t & 1);
+    if (!(ABL & 32) && t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
     if (t * kTK < my_keys) {
       // ---- S^T = K Q^T: 4 chunks of 16 dims x 6 piece products --------------------------------
       f32x16 s = {0};
@@ -332,33 +345,46 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) ak[p] = __builtin_bit_cast(bf16x8, sK[buf][p * 8 + c * 2 + h][j]);
 #define PTOPS_QK(PA, PB) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak[PA], bq[PB][c], s, 0, 0, 0);
-        PTOPS_SPLIT3_TERMS(PTOPS_QK)
+        if (!(ABL & 8)) { PTOPS_SPLIT3_TERMS(PTOPS_QK) } else { s[c] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, ak[0]).x & 0x3f800000u); }
 #undef PTOPS_QK
       }
       // ---- online softmax (query = lane&31; this half holds 16 of the tile's 32 keys) ------
+      if (!(ABL & 4)) {
       float mt = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
       mt = fmaxf(mt, other_half(mt));
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      // Deferred rescaling: the running reference m_run only has to be an upper bound "within reach" of every score, not
+      // the exact maximum - exp2(s - m_run) of a tile whose maximum exceeds m_run by <= 6 is at most 64, far from any
+      // fp32 trouble, and O and l are accumulated against the same reference, so the quotient at the end is the same
+      // function.  The wave rescales O (32 multiplies, an exp2) only when some query's maximum outgrows the reference by
+      // more than that (wave-uniform branch); on trained or random scores that is the first tile and a handful after it.
+      if (__builtin_amdgcn_ballot_w64(mt > m_run + 6.0f)) {
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
+        o0 *= alpha;
+        o1 *= alpha;
+      }
       float psum = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
         psum += s[r];
       }
-      l_run = l_run * alpha + psum;  // per-half partial sum; halves are added at the end
-      m_run = m_new;
-      o0 *= alpha;
-      o1 *= alpha;
+      l_run += psum;  // per-half partial sum; halves are added at the end
+      } else {
+        l_run += s[0];
+        m_run = 0.0f;
+      }
       // ---- O^T += V^T P: 2 k-steps of 16 keys x 2 dim blocks x 6 piece products -----------------
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float px[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) px[i] = s[8 * ks + i];
-        const Pieces3 pp = split8(px);
+        const Pieces3 pp = (ABL & 2) ? cheap8(px) : split8(px);
         const bf16x8 bp[3] = {__builtin_bit_cast(bf16x8, pp.h), __builtin_bit_cast(bf16x8, pp.m), __builtin_bit_cast(bf16x8, pp.l)};
         bf16x8 av0[3], av1[3];
 #pragma unroll
@@ -369,11 +395,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
 #define PTOPS_PV(PA, PB)                                                          \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0[PA], bp[PB], o0, 0, 0, 0); \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1[PA], bp[PB], o1, 0, 0, 0);
-        PTOPS_SPLIT3_TERMS(PTOPS_PV)
+        if (!(ABL & 16)) { PTOPS_SPLIT3_TERMS(PTOPS_PV) } else {
+          o0[ks] += __builtin_bit_cast(float, (__builtin_bit_cast(uint4, av0[0]).x ^ __builtin_bit_cast(uint4, bp[1]).y) & 0x3f800000u);
+          o1[ks] += __builtin_bit_cast(float, (__builtin_bit_cast(uint4, av1[2]).x ^ __builtin_bit_cast(uint4, bp[2]).y) & 0x3f800000u);
+        }
 #undef PTOPS_PV
       }
     }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (!(ABL & 32) && t + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -1393,7 +1422,14 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   // >= 4 query tiles: the bf16-matrix-pipe kernel (fp32-accurate three-piece split, attn_fwd_split3_kernel);
   // PTOPS_ATTN_FWD_F32=1 keeps the f32-MFMA kernel
   if (tiles >= 4 && !ptops::option("PTOPS_ATTN_FWD_F32")) {
-    hipLaunchKernelGGL(attn_fwd_split3_kernel, dim3(ptops::ceil_div(tiles, 4), B * H), dim3(256), 0, stream, a);
+    const dim3 grid(ptops::ceil_div(tiles, 4), B * H);
+    switch (ptops::option("PTOPS_ATTN_FWD_ABL")) {       // timing experiments (wrong results): see the kernel's header
+#define PTOPS_ABL_CASE(N) case N: hipLaunchKernelGGL(attn_fwd_split3_kernel<N>, grid, dim3(256), 0, stream, a); break;
+      PTOPS_ABL_CASE(1) PTOPS_ABL_CASE(2) PTOPS_ABL_CASE(3) PTOPS_ABL_CASE(4) PTOPS_ABL_CASE(7) PTOPS_ABL_CASE(8)
+      PTOPS_ABL_CASE(16) PTOPS_ABL_CASE(24) PTOPS_ABL_CASE(32) PTOPS_ABL_CASE(35) PTOPS_ABL_CASE(39) PTOPS_ABL_CASE(63)
+#undef PTOPS_ABL_CASE
+      default: hipLaunchKernelGGL(attn_fwd_split3_kernel<0>, grid, dim3(256), 0, stream, a); break;
+    }
     return ptops::check_launch("attn_fwd_split3_kernel");
   }
   int W = tiles < 4 ? tiles : 4;
