@@ -257,7 +257,7 @@ __device__ __forceinline__ Pieces3 cheap8(const float (&x)[8]) {
   return p;
 }
 
-template <int ABL>
+template <int ABL, bool LATE = true, bool PRIO = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
   constexpr int W = 4;
   constexpr int kKRow = 33;                                  // padded: conflict-free ds_write_b128 of 8 lanes per key
@@ -327,18 +327,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
     sV[buf][2 * 4 + v_sh][v_dim] = pv.l;
   };
 
+  // Staging order (round 4): a tile's global loads are issued a whole iteration before they are needed, and its split +
+  // LDS writes come right AFTER the barrier that frees the other buffer, not in front of the next one - the writes'
+  // latency then passes under this iteration's fragment reads and MFMAs instead of under a wait for lgkmcnt(0) that every
+  // wave of the workgroup sits through at the barrier (the guide's issue-early / write-late split).
   const int ntiles = blk_keys / kTK;
   if (ntiles > 0) {
     fetch_tile(0);
     store_tile(0);
+    if (LATE && !(ABL & 32) && ntiles > 1) fetch_tile(kTK);
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = (ABL & 32) ? 0 : (t & 1);
-    if (!(ABL & 32) && t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    if (LATE && !(ABL & 32) && t + 1 < ntiles) {
+      store_tile(buf ^ 1);                                   // tile t + 1: its buffer was last read before the barrier just passed
+      if (t + 2 < ntiles) fetch_tile((t + 2) * kTK);         // in flight during the MFMAs below and the next store's barrier
+    }
+    if (!LATE && !(ABL & 32) && t + 1 < ntiles) fetch_tile((t + 1) * kTK);
     if (t * kTK < my_keys) {
       // ---- S^T = K Q^T: 4 chunks of 16 dims x 6 piece products --------------------------------
       f32x16 s = {0};
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         bf16x8 ak[3];
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
         if (!(ABL & 8)) { PTOPS_SPLIT3_TERMS(PTOPS_QK) } else { s[c] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, ak[0]).x & 0x3f800000u); }
 #undef PTOPS_QK
       }
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
       // ---- online softmax (query = lane&31; this half holds 16 of the tile's 32 keys) ------
       if (!(ABL & 4)) {
       float mt = s[0];
@@ -395,14 +406,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_split3_kernel(AttnArgs a) {
 #define PTOPS_PV(PA, PB)                                                          \
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0[PA], bp[PB], o0, 0, 0, 0); \
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1[PA], bp[PB], o1, 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
         if (!(ABL & 16)) { PTOPS_SPLIT3_TERMS(PTOPS_PV) } else {
           o0[ks] += __builtin_bit_cast(float, (__builtin_bit_cast(uint4, av0[0]).x ^ __builtin_bit_cast(uint4, bp[1]).y) & 0x3f800000u);
           o1[ks] += __builtin_bit_cast(float, (__builtin_bit_cast(uint4, av1[2]).x ^ __builtin_bit_cast(uint4, bp[2]).y) & 0x3f800000u);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
 #undef PTOPS_PV
       }
     }
-    if (!(ABL & 32) && t + 1 < ntiles) store_tile(buf ^ 1);
+    if (!LATE && !(ABL & 32) && t + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -749,6 +762,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_bwd_dkv_kernel(AttnBwdArgs a) 
 //                       16 s + 8 (jj >> 2) + 4 h + (jj & 3): A operand of contractions over the tile rows (dQ^T, dK^T,
 //                       dV^T), in exactly the order in which an S / dP accumulator hands its rows over as the B operand.
 // The stationary operand (Q, dO for dq; K, V for dkv) is split once into 2 x 48 VGPRs.
+template <bool LATE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs a) {
   constexpr int W = 4;
   constexpr int kRow = 33;
@@ -851,15 +865,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs 
     sT[buf][2 * 4 + t_sh][t_dim] = pt.l;
   };
 
+  // staging order as in attn_fwd_split3_kernel: loads a whole iteration ahead, split + LDS writes right after the barrier
   const int ntiles = blk_keys / kTK;
   if (ntiles > 0) {
     fetch_tile(0);
     store_tile(0);
+    if (LATE && ntiles > 1) fetch_tile(kTK);
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) fetch_tile((t + 1) * kTK);  // in flight during the MFMAs below
+    if (LATE && t + 1 < ntiles) {
+      store_tile(buf ^ 1);
+      if (t + 2 < ntiles) fetch_tile((t + 2) * kTK);
+    }
+    if (!LATE && t + 1 < ntiles) fetch_tile((t + 1) * kTK);
     if (t * kTK < my_keys) {
       // ---- S^T = K Q^T, dP^T = V dO^T: 4 chunks of 16 dims x 6 piece products each ---------------------
       f32x16 s = {0}, dp = {0};
@@ -900,7 +920,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs 
 #undef PTOPS_DQ
       }
     }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
+    if (!LATE && t + 1 < ntiles) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -908,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split3_kernel(AttnBwdArgs 
     store_dim_major(a.dq + b * a.dq_sb + head * a.dq_sh + (long long)(q0 + j) * a.dq_sn, g0, g1, h, a.scale);
 }
 
-template <int W>
+template <int W, bool LATE>
 __global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs a) {
   constexpr int kRow = 33;
   __shared__ uint4 sR[2][2][3 * 4 * 2][kRow];                // [buf][Q | dO][(piece*4 + chunk)*2 + half][query]
@@ -1011,15 +1031,21 @@ __global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs
     if (tid < 64) sL[buf][tid] = lreg;
   };
 
+  // staging order as in attn_fwd_split3_kernel: loads a whole iteration ahead, split + LDS writes right after the barrier
   const int t_begin = blk_qstart / kTK, t_end = a.Nq / kTK;
   if (t_begin < t_end) {
     fetch_tile(t_begin * kTK);
     store_tile(t_begin & 1);
+    if (LATE && t_begin + 1 < t_end) fetch_tile((t_begin + 1) * kTK);
   }
   __syncthreads();
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = t & 1;
-    if (t + 1 < t_end) fetch_tile((t + 1) * kTK);
+    if (LATE && t + 1 < t_end) {
+      store_tile(buf ^ 1);
+      if (t + 2 < t_end) fetch_tile((t + 2) * kTK);
+    }
+    if (!LATE && t + 1 < t_end) fetch_tile((t + 1) * kTK);
     if (t * kTK >= my_qstart) {
       // ---- S = Q K^T, dP = dO V^T  (rows = queries (r&3)+8(r>>2)+4h, column = key j) --------------
       f32x16 s = {0}, dp = {0};
@@ -1096,7 +1122,7 @@ __global__ __launch_bounds__(W * 64) void attn_bwd_dkv_split3_kernel(AttnBwdArgs
         }
       }
     }
-    if (t + 1 < t_end) store_tile(buf ^ 1);
+    if (!LATE && t + 1 < t_end) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -1428,7 +1454,11 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
       PTOPS_ABL_CASE(1) PTOPS_ABL_CASE(2) PTOPS_ABL_CASE(3) PTOPS_ABL_CASE(4) PTOPS_ABL_CASE(7) PTOPS_ABL_CASE(8)
       PTOPS_ABL_CASE(16) PTOPS_ABL_CASE(24) PTOPS_ABL_CASE(32) PTOPS_ABL_CASE(35) PTOPS_ABL_CASE(39) PTOPS_ABL_CASE(63)
 #undef PTOPS_ABL_CASE
-      default: hipLaunchKernelGGL(attn_fwd_split3_kernel<0>, grid, dim3(256), 0, stream, a); break;
+      default:
+        if (ptops::option("PTOPS_ATTN_PRIO")) hipLaunchKernelGGL((attn_fwd_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, a);
+        else if (ptops::option("PTOPS_ATTN_STAGE_EARLY")) hipLaunchKernelGGL((attn_fwd_split3_kernel<0, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_split3_kernel<0, true>), grid, dim3(256), 0, stream, a);
+        break;
     }
     return ptops::check_launch("attn_fwd_split3_kernel");
   }
@@ -1484,15 +1514,21 @@ PTOPS_API int ptops_attention_backward(const float* q, const float* k, const flo
   // the f32-MFMA kernels for A/B runs
   const bool f32_only = ptops::option("PTOPS_ATTN_BWD_F32") != 0;
   if (!f32_only && Nq >= 128 && Nk >= 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_split3_kernel, dim3(ptops::ceil_div(Nq / 32, 4), B * H), dim3(256), 0, stream, a);
+    const bool late = !ptops::option("PTOPS_ATTN_STAGE_EARLY");     // A/B switch: split + LDS writes before the barrier
+    if (late) hipLaunchKernelGGL(attn_bwd_dq_split3_kernel<true>, dim3(ptops::ceil_div(Nq / 32, 4), B * H), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_split3_kernel<false>, dim3(ptops::ceil_div(Nq / 32, 4), B * H), dim3(256), 0, stream, a);
     int rc = ptops::check_launch("attn_bwd_dq_split3_kernel");
     if (rc != PTOPS_OK) return rc;
     const int ktiles = Nk / 32;
     const int dkv_waves = ptops::option("PTOPS_ATTN_DKV_WAVES") == 4 ? 4 : 8;
-    if (dkv_waves == 4)
-      hipLaunchKernelGGL(attn_bwd_dkv_split3_kernel<4>, dim3(ptops::ceil_div(ktiles, 4), B * H), dim3(256), 0, stream, a);
+    if (dkv_waves == 4 && late)
+      hipLaunchKernelGGL((attn_bwd_dkv_split3_kernel<4, true>), dim3(ptops::ceil_div(ktiles, 4), B * H), dim3(256), 0, stream, a);
+    else if (dkv_waves == 4)
+      hipLaunchKernelGGL((attn_bwd_dkv_split3_kernel<4, false>), dim3(ptops::ceil_div(ktiles, 4), B * H), dim3(256), 0, stream, a);
+    else if (late)
+      hipLaunchKernelGGL((attn_bwd_dkv_split3_kernel<8, true>), dim3(ptops::ceil_div(ktiles, 8), B * H), dim3(512), 0, stream, a);
     else
-      hipLaunchKernelGGL(attn_bwd_dkv_split3_kernel<8>, dim3(ptops::ceil_div(ktiles, 8), B * H), dim3(512), 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_split3_kernel<8, false>), dim3(ptops::ceil_div(ktiles, 8), B * H), dim3(512), 0, stream, a);
     return ptops::check_launch("attn_bwd_dkv_split3_kernel");
   }
   {  // dq (+ delta): one wave per 32-query tile; two waves per SIMD fit, so 4-wave workgroups (two per CU)
