@@ -355,3 +355,52 @@ def test_inference_cli_matches_the_reference_on_the_hip_path(native, tmp_path):
     """tools/inference.py end to end on the GPU (graphed eval forward) against the reference's fine.npy."""
     import parity_checks as pc
     print(pc.check_inference("cuda", tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_graphed_train_step_recaptures_when_a_baked_scalar_changes(native):
+    """The epoch-dependent coarse-loss weight of the VariableLoss models and the BatchNorm momenta (changed by the runner's
+    scheduler between epochs) are Python numbers that a captured launch sequence bakes in: `GraphedTrainStep` keys its
+    graphs on them.  Image model, B = 2: five steps at epoch 0, six at epoch 1 (another loss weight), then three with another
+    BatchNorm momentum - three graphs, each preceded by its own eager steps, losses equal to the eager run throughout."""
+    import parity_checks as pc
+    from imgadapointr_amd.tools import builder, runner
+    from imgadapointr_amd.utils.graph_runner import GraphedTrainStep
+    B = 2
+    plan = [0] * 5 + [1] * 6 + [1] * 5          # epochs; the momentum changes before the last five steps
+
+    def run(graphed):
+        model, cfg, spec = pc.build_trainstep_model("img", "cuda")
+        model.train()
+        step = runner.TrainStep(model, builder.build_optimizer(model, cfg), 10, 1)
+        assert model.coarse_loss_weight(0) != model.coarse_loss_weight(1)
+        if graphed:
+            step = GraphedTrainStep(step, warmup=3, verify=True, max_graphs=2)
+        losses = []
+        for i, epoch in enumerate(plan):
+            if i == 11:
+                for m in model.modules():
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                        m.momentum = 0.05
+            torch.manual_seed(2000 + i)
+            g = torch.Generator().manual_seed(300 + i)
+            partial = (torch.rand(B, 2048, 3, generator=g) - 0.5).cuda()
+            gt = (torch.rand(B, 16384, 3, generator=g) - 0.5).cuda()
+            img = torch.rand(B, 3, 224, 224, generator=g).cuda()
+            l0, l1 = step(partial, gt, (img,), epoch)
+            losses.append((l0.item(), l1.item()))
+        return step, losses, {n: b.detach().clone() for n, b in model.named_buffers() if "running_mean" in n}
+
+    with pc._Pinned():
+        _, le, be = run(False)
+        gs, lg, bg = run(True)
+    assert gs.enabled, gs.disabled_reason
+    # per key: three eager steps, the capture (its check replays once), then replays
+    assert gs.replays == (5 - 3) + (6 - 3) + (5 - 3), gs.replays
+    assert len(gs._cache) == 2                                   # max_graphs = 2: the epoch-0 graph was dropped
+    for (a0, a1), (b0, b1) in zip(le, lg):
+        assert abs(a0 - b0) <= 1e-4 * abs(a0) and abs(a1 - b1) <= 1e-4 * abs(a1), (le, lg)
+    # the changed momentum reached the replayed BatchNorm launches: running statistics follow the eager run
+    for n in be:
+        assert torch.allclose(be[n], bg[n], rtol=1e-3, atol=1e-5), n
