@@ -24,6 +24,13 @@ from .Transformer_utils import LayerNorm, add_layer_norm
 # activation is ever padded or sliced.  Zero dims add nothing to q.k and produce zero output dims: same function.
 PADDED_HEAD_MFMA_ATTENTION = True
 _PAD = 64
+# True: while a HIP graph is being captured (utils/graph_runner.py::GraphedTrainStep) the image encoder runs on a side
+# stream that forks at the start of the forward and joins where its tokens are first needed, i.e. as a parallel branch
+# of the graph beside the grouper and the point encoder (FPS occupies 32 of 256 CUs for 0.3 ms, kNN and the edge-conv
+# stages are small launches); autograd runs its backward on that stream too.  In eager mode the same fork / join costs
+# more in cross-stream events than the idle CUs are worth, so it is used under capture only.
+import os as _os
+OVERLAP_IMAGE_BRANCH = _os.environ.get("PTOPS_OVERLAP_IMAGE_BRANCH", "1") != "0"
 
 
 def _pad_head_rows(w, parts, heads, d):
@@ -117,9 +124,17 @@ class PCTransformer(_PointTrunk):
         return self.get_better_seg_size(seg_emb.transpose(1, 2))
 
     # hooks called by the point trunk ---------------------------------------------------------
+    def _image_tokens(self, img):
+        return self.get_better_img_size(self.im_encoder(img))                           # [B,256,384]
+
     def fuse_encoder_tokens(self, x, coor, img, cls_vec):
         if self.use_img:
-            img_feat = self.get_better_img_size(self.im_encoder(img))                   # [B,256,384]
+            ahead = self.__dict__.pop('_img_ahead', None)
+            if ahead is not None:                    # computed on the side stream since the start of the forward
+                img_feat, side = ahead
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                img_feat = self._image_tokens(img)
             x = self._fuse(x, img_feat, 'img')
         if self.use_seg and getattr(self.config, 'seg_before_enc', False) and cls_vec is not None:
             x = self._fuse(x, self._seg_tokens(coor, cls_vec), 'seg')
@@ -134,4 +149,18 @@ class PCTransformer(_PointTrunk):
         return fused if denoise_length == 0 else torch.cat([fused, q[:, n:]], dim=1)
 
     def forward(self, xyz, img=None, cls_vec=None, denoise_noise=None):
-        return super().forward(xyz, denoise_noise=denoise_noise, img=img, cls_vec=cls_vec)
+        if (OVERLAP_IMAGE_BRANCH and self.use_img and img is not None and img.is_cuda and img.dim() == 4
+                and torch.cuda.is_current_stream_capturing()):
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get('_side_stream')
+            if side is None or side.device != img.device:
+                side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=img.device)
+            side.wait_stream(main)                   # fork: joins the capture
+            with torch.cuda.stream(side):
+                self.__dict__['_img_ahead'] = (self._image_tokens(img), side)
+        try:
+            return super().forward(xyz, denoise_noise=denoise_noise, img=img, cls_vec=cls_vec)
+        finally:
+            ahead = self.__dict__.pop('_img_ahead', None)
+            if ahead is not None:                    # the trunk never asked for the tokens: still join the capture
+                torch.cuda.current_stream().wait_stream(ahead[1])
