@@ -442,5 +442,8 @@ class GraphedTrainStep:
     # +-lr step of that element - so losses and the gradient norm are compared relatively and the first parameters after
     # the update by their MEAN distance in units of the learning rate (a few flipped elements do not move it; a wrong
     # table or a stale graph node does).
-    verify_floor = {"loss": 1e-5, "grad_norm": 1e-4, "update_mean_over_lr": 2e-3}
+    # floors: the image variant at bs 16 read up to 3e-5 / 3.4e-4 / 2.2e-3 on boxes where its two eager runs happened to land
+    # closer to each other than that (a two-sample yardstick); a graph that replays stale or wrong data is orders away
+    # (a wrong optimizer table moves every element by ~lr: update_mean_over_lr ~ 1; stale nodes gave loss differences of 1e-2)
+    verify_floor = {"loss": 1e-4, "grad_norm": 1e-3, "update_mean_over_lr": 1e-2}
     verify_ceiling = {"loss": 1e-2, "grad_norm": 5e-2, "update_mean_over_lr": 5e-2}
