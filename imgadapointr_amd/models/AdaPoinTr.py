@@ -116,6 +116,10 @@ class PCTransformer(nn.Module):
     def fuse_decoder_tokens(self, q, coarse, denoise_length, cls_vec):
         return q
 
+    def begin_decoder_side_branch(self, coarse, denoise_length, cls_vec):
+        """Called as soon as the query coordinates exist (before the query MLP and the decoder): a fusion trunk may start
+        work that depends on them only (models/pctransformer.py)."""
+
     def forward(self, xyz, denoise_noise=None, img=None, cls_vec=None):
         """xyz [B,N,3] -> (q [B,M,C], coarse [B,M,3], denoise_length).
 
@@ -174,6 +178,7 @@ class PCTransformer(nn.Module):
         else:
             denoise_length = 0
 
+        self.begin_decoder_side_branch(coarse, denoise_length, cls_vec)
         # mlp_query(cat([global_feature broadcast, coarse])) with its first Linear split
         q = linear_on_broadcast_concat(self.mlp_query[0], global_feature, coarse)
         for layer in list(self.mlp_query)[1:]:

@@ -29,7 +29,7 @@ _PAD = 64
 # of the graph beside the grouper and the point encoder (FPS occupies 32 of 256 CUs for 0.3 ms, kNN and the edge-conv
 # stages are small launches); autograd runs its backward on that stream too.  In eager mode the same fork / join costs
 # more in cross-stream events than the idle CUs are worth, so it is used under capture only.
-import os as _os
+import os as _os  # noqa: E402
 OVERLAP_IMAGE_BRANCH = _os.environ.get("PTOPS_OVERLAP_IMAGE_BRANCH", "1") != "0"
 
 
@@ -140,11 +140,36 @@ class PCTransformer(_PointTrunk):
             x = self._fuse(x, self._seg_tokens(coor, cls_vec), 'seg')
         return x
 
+    def _side_stream_for(self, t):
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != t.device:
+            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=t.device)
+        return side
+
+    def begin_decoder_side_branch(self, coarse, denoise_length, cls_vec):
+        """Segmentation after the decoder (`seg_before_dec`): GDANet's part embeddings depend on the query coordinates only,
+        which exist before the query MLP and the eight decoder blocks.  Under graph capture they are computed on the side
+        stream as a parallel branch beside the decoder (normals + GDANet are ~1 150 small launches that leave most of the
+        chip idle; the decoder's GEMM / attention launches do not), and joined in `fuse_decoder_tokens`."""
+        if not (OVERLAP_IMAGE_BRANCH and self.use_seg and getattr(self.config, 'seg_before_dec', False) and cls_vec is not None
+                and coarse.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return
+        side = self._side_stream_for(coarse)
+        side.wait_stream(torch.cuda.current_stream())
+        n = coarse.size(1) - denoise_length
+        with torch.cuda.stream(side):
+            self.__dict__['_seg_ahead'] = (self._seg_tokens(coarse[:, :n], cls_vec), side)
+
     def fuse_decoder_tokens(self, q, coarse, denoise_length, cls_vec):
         if not (self.use_seg and getattr(self.config, 'seg_before_dec', False) and cls_vec is not None):
             return q
         n = coarse.size(1) - denoise_length            # only the real queries are enhanced
-        seg = self._seg_tokens(coarse[:, :n], cls_vec)
+        ahead = self.__dict__.pop('_seg_ahead', None)
+        if ahead is not None:
+            seg = ahead[0]
+            torch.cuda.current_stream().wait_stream(ahead[1])
+        else:
+            seg = self._seg_tokens(coarse[:, :n], cls_vec)
         fused = self._fuse(q[:, :n], seg, 'seg')
         return fused if denoise_length == 0 else torch.cat([fused, q[:, n:]], dim=1)
 
@@ -152,15 +177,14 @@ class PCTransformer(_PointTrunk):
         if (OVERLAP_IMAGE_BRANCH and self.use_img and img is not None and img.is_cuda and img.dim() == 4
                 and torch.cuda.is_current_stream_capturing()):
             main = torch.cuda.current_stream()
-            side = self.__dict__.get('_side_stream')
-            if side is None or side.device != img.device:
-                side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=img.device)
+            side = self._side_stream_for(img)
             side.wait_stream(main)                   # fork: joins the capture
             with torch.cuda.stream(side):
                 self.__dict__['_img_ahead'] = (self._image_tokens(img), side)
         try:
             return super().forward(xyz, denoise_noise=denoise_noise, img=img, cls_vec=cls_vec)
         finally:
-            ahead = self.__dict__.pop('_img_ahead', None)
-            if ahead is not None:                    # the trunk never asked for the tokens: still join the capture
-                torch.cuda.current_stream().wait_stream(ahead[1])
+            for key in ('_img_ahead', '_seg_ahead'):
+                ahead = self.__dict__.pop(key, None)
+                if ahead is not None:                # the trunk never asked for the tokens: still join the capture
+                    torch.cuda.current_stream().wait_stream(ahead[1])
