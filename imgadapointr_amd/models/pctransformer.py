@@ -133,6 +133,7 @@ class PCTransformer(_PointTrunk):
             if ahead is not None:                    # computed on the side stream since the start of the forward
                 img_feat, side = ahead
                 torch.cuda.current_stream().wait_stream(side)
+                img_feat.record_stream(torch.cuda.current_stream())      # allocated there, read here: no early reuse
             else:
                 img_feat = self._image_tokens(img)
             x = self._fuse(x, img_feat, 'img')
@@ -156,6 +157,7 @@ class PCTransformer(_PointTrunk):
             return
         side = self._side_stream_for(coarse)
         side.wait_stream(torch.cuda.current_stream())
+        coarse.record_stream(side)                   # allocated on the main stream, read (and saved for backward) on the side one
         n = coarse.size(1) - denoise_length
         with torch.cuda.stream(side):
             self.__dict__['_seg_ahead'] = (self._seg_tokens(coarse[:, :n], cls_vec), side)
@@ -168,6 +170,7 @@ class PCTransformer(_PointTrunk):
         if ahead is not None:
             seg = ahead[0]
             torch.cuda.current_stream().wait_stream(ahead[1])
+            seg.record_stream(torch.cuda.current_stream())               # allocated there, read here: no early reuse
         else:
             seg = self._seg_tokens(coarse[:, :n], cls_vec)
         fused = self._fuse(q[:, :n], seg, 'seg')
