@@ -60,7 +60,10 @@ def furthest_point_sample_async(xyz, npoint):
     """`furthest_point_sample(xyz, npoint)` started on a side stream of xyz's device (CUDA tensors; elsewhere it simply
     runs) -> FpsHandle.  The side stream first waits for the work already queued on the current stream (which produces
     xyz), and `result()` joins it again, so the pattern is also valid inside a HIP-graph capture."""
-    if not (OVERLAP_FPS and xyz.is_cuda and _native.backend_for_testing() is None):
+    # Inside a HIP-graph capture (utils/graph_runner.py) the fork / join is a pair of graph edges and the sampling becomes
+    # a parallel branch beside the first kNN / edge-conv launches: always taken there.  In eager mode only on request.
+    if not (xyz.is_cuda and _native.backend_for_testing() is None
+            and (OVERLAP_FPS or _torch.cuda.is_current_stream_capturing())):
         return FpsHandle(furthest_point_sample(xyz, npoint))
     dev = xyz.device
     cur = _torch.cuda.current_stream(dev)
