@@ -314,7 +314,7 @@ class GraphedTrainStep:
                 t.copy_(s)
         torch.cuda.set_rng_state(rng, tensors[0].device)
 
-    def _capture(self, tensors, epoch, has_noise, n_extra):
+    def _capture(self, tensors, epoch, has_noise, n_extra, slots):
         """-> cache entry, or None (graphing disabled).  The captured step has NOT run when this returns."""
         from .. import _native
         opt = self.step.optimizer
@@ -326,7 +326,10 @@ class GraphedTrainStep:
         state = self._state
         static = [t.clone() for t in tensors]
         partial, gt = static[0], static[1]
-        extra = tuple(static[2:2 + n_extra])
+        extra = [None] * n_extra
+        for j, i in enumerate(slots):
+            extra[i] = static[2 + j]
+        extra = tuple(extra)
         noise = static[-1] if has_noise else None
         self.step.zero_grad()
         graph = torch.cuda.CUDAGraph()
@@ -356,8 +359,10 @@ class GraphedTrainStep:
     def __call__(self, partial, gt, extra=(), epoch=0, denoise_noise=None):
         from .. import _native
         extra = tuple(extra)
-        tensors = [partial, gt] + [t for t in extra]
-        if any(not isinstance(t, torch.Tensor) for t in tensors) or not self._eligible(tensors):
+        slots = tuple(i for i, t in enumerate(extra) if isinstance(t, torch.Tensor))   # a model may take None for an input
+        tensors = [partial, gt] + [extra[i] for i in slots]
+        if (not isinstance(partial, torch.Tensor) or not isinstance(gt, torch.Tensor)
+                or any(t is not None and not isinstance(t, torch.Tensor) for t in extra) or not self._eligible(tensors)):
             return self.step(partial, gt, extra, epoch, denoise_noise)
         device = partial.device
         with torch.cuda.device(device):
@@ -366,7 +371,7 @@ class GraphedTrainStep:
             has_noise = denoise_noise is not None
             if has_noise:
                 tensors = tensors + [denoise_noise]
-            key = (signature(tensors), self._host_scalars(epoch), len(extra), has_noise)
+            key = (signature(tensors), self._host_scalars(epoch), len(extra), slots, has_noise)
             entry = self._cache.get(key)
             if entry is not None:
                 self._cache.move_to_end(key)
@@ -389,7 +394,7 @@ class GraphedTrainStep:
                 self._disable("HIP-graph memset nodes do not replay reliably in this process (set "
                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first GPU call: imgadapointr_amd/__init__.py)")
                 return self.step(partial, gt, extra, epoch, denoise_noise)
-            entry = self._capture(tensors, epoch, has_noise, len(extra))
+            entry = self._capture(tensors, epoch, has_noise, len(extra), slots)
             if entry is None:
                 return self.step(partial, gt, extra, epoch, denoise_noise)
             if self.verify:

@@ -269,7 +269,7 @@ def test_train_step_gradients_are_bit_reproducible(native):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("case", ["adapointr", "img", "seg"])
+@pytest.mark.parametrize("case", ["adapointr", "img", "seg", "segenc"])
 def test_graphed_train_step_equals_eager(native, case):
     """`GraphedTrainStep` (the whole train step replayed from one HIP graph; utils/graph_runner.py) against the eager
     `TrainStep` from identical weights over seven steps with fresh inputs each step, an LR change and host
@@ -338,7 +338,7 @@ def test_graphed_train_step_equals_eager(native, case):
         # seg: GDANet in train mode over B = 2 (feature-space top-k at near-ties, a max-pool backward without a deterministic
         # form) amplifies rounding-level differences over the steps (its arms differ from each other by
         # percents in the gradient), and its branch runs beside the decoder inside the graph; 3e-4 was seen at step 6
-        tol = 1e-3 if case == "seg" else 1e-4
+        tol = 1e-3 if case in ("seg", "segenc") else 1e-4
         for (a0, a1), (b0, b1) in zip(le, lg):
             assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (le, lg)
         lr = 1e-4
