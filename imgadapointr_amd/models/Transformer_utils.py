@@ -767,25 +767,36 @@ class CrossAttention(nn.Module):
         self.proj = Linear(out_dim, out_dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, q, v):
+    def project_kv(self, k, n_queries):
+        """k_map and v_map of the keys / values as ONE projection on the concatenated weights -> packed [B,M,2,h,64] for
+        `_MFMAKVAttention`, or None where that form does not apply (the caller then runs the two maps).  A separate step so
+        that a decoder can run it for all its blocks ahead of the query chain (the memory does not depend on the queries)."""
+        B, NK, _ = k.shape
+        C, h = self.out_dim, self.num_heads
+        if not (FUSED_KV_PROJECTION and USE_MFMA_ATTENTION and USE_MFMA_ATTENTION_BWD and C // h == 64 and k.is_cuda
+                and k.dtype == torch.float32 and _native.backend_for_testing() is None and torch.is_grad_enabled()
+                and self.k_map.bias is not None and self.v_map.bias is not None and B * NK >= 2048
+                and (self.attn_drop.p == 0.0 or not self.training) and n_queries % 32 == 0 and NK % 32 == 0):
+            return None
+        wkv = torch.cat([self.k_map.weight, self.v_map.weight], dim=0)            # [2C, C]: 1.2 MB, once per call
+        bkv = torch.cat([self.k_map.bias, self.v_map.bias], dim=0)
+        wkv._ptops_keys = (self.k_map.weight.data_ptr(), self.v_map.weight.data_ptr())
+        bkv._ptops_keys = (self.k_map.bias.data_ptr(), self.v_map.bias.data_ptr())
+        # the weight / bias gradients travel on through cat's backward as two dim-0 views each, which AccumulateGrad
+        # adopts without reading (dense, strides of the parameter, sole owner): they may stay queued (deferred
+        # folds / grouped weight gradients; test_cross_attention_fused_kv_projection runs this with poisoned outputs)
+        return _LinearFn.apply(k.reshape(B * NK, -1), wkv, bkv).view(B, NK, 2, h, C // h)
+
+    def forward(self, q, v, kv=None):
         B, N, _ = q.shape
         C = self.out_dim
         k = v
         NK = k.size(1)
         h = self.num_heads
         q = self.q_map(q).view(B, N, h, C // h).permute(0, 2, 1, 3)
-        if (FUSED_KV_PROJECTION and USE_MFMA_ATTENTION and USE_MFMA_ATTENTION_BWD and C // h == 64 and k.is_cuda
-                and k.dtype == torch.float32 and _native.backend_for_testing() is None and torch.is_grad_enabled()
-                and self.k_map.bias is not None and self.v_map.bias is not None and B * NK >= 2048
-                and (self.attn_drop.p == 0.0 or not self.training) and N % 32 == 0 and NK % 32 == 0):
-            wkv = torch.cat([self.k_map.weight, self.v_map.weight], dim=0)            # [2C, C]: 1.2 MB, once per call
-            bkv = torch.cat([self.k_map.bias, self.v_map.bias], dim=0)
-            wkv._ptops_keys = (self.k_map.weight.data_ptr(), self.v_map.weight.data_ptr())
-            bkv._ptops_keys = (self.k_map.bias.data_ptr(), self.v_map.bias.data_ptr())
-            # the weight / bias gradients travel on through cat's backward as two dim-0 views each, which AccumulateGrad
-            # adopts without reading (dense, strides of the parameter, sole owner): they may stay queued (deferred
-            # folds / grouped weight gradients; test_cross_attention_fused_kv_projection runs this with poisoned outputs)
-            kv = _LinearFn.apply(k.reshape(B * NK, -1), wkv, bkv).view(B, NK, 2, h, C // h)
+        if kv is None:
+            kv = self.project_kv(k, N)
+        if kv is not None:
             x = _MFMAKVAttention.apply(q, kv, self.scale).reshape(B, N, C)
             return self.proj_drop(self.proj(x))
         k = self.k_map(k).view(B, NK, h, C // h).permute(0, 2, 1, 3)

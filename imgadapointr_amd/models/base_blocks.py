@@ -23,6 +23,10 @@ from .Transformer_utils import (Attention, CrossAttention, DynamicGraphAttention
                                 knn_idx, linear_on_broadcast_concat, max_over_tokens)
 
 _VALID_TOKENS = ('attn', 'rw_deform', 'deform', 'graph', 'deform_graph')
+# the decoder's memory side as a parallel graph branch (TransformerDecoder.forward); PTOPS_OVERLAP_DECODER_MEMORY=0: off
+import os as _os  # noqa: E402
+OVERLAP_DECODER_MEMORY = _os.environ.get("PTOPS_OVERLAP_DECODER_MEMORY", "1") != "0"
+_memory_streams = {}
 
 
 def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
@@ -206,10 +210,20 @@ class CrossAttnBlockApi(nn.Module):
         mask[:-denoise_length, -denoise_length:] = 1.
         return mask
 
+    def memory_side(self, v, n_queries):
+        """What this block computes from the memory `v` alone: norm_v(v) and, where the packed form applies, the k / v
+        projections of its global cross attention -> (norm_v, kv or None).  None if the block does not take that path."""
+        if self.cross_attn_block_length == 2 and self.cross_attn_combine_style == 'onebyone':
+            return None
+        norm_v = self.norm_v(v)
+        kv = self.cross_attn.project_kv(norm_v, n_queries) if self.cross_attn is not None else None
+        return norm_v, kv
+
     def forward(self, q, v, q_pos, v_pos, self_attn_idx=None, cross_attn_idx=None, denoise_length=None,
-                denoise_mask=None, normed=None, next_norm=None):
+                denoise_mask=None, normed=None, next_norm=None, memory=None):
         """`denoise_mask`: the mask above, if the caller already built it (it is the same for every block).
-        `normed` / `next_norm`: as in SelfAttnBlockApi.forward (norm1 of this / of the following block)."""
+        `normed` / `next_norm`: as in SelfAttnBlockApi.forward (norm1 of this / of the following block).
+        `memory`: (norm_v, kv, event) of `memory_side`, computed ahead on another stream (TransformerDecoder.forward)."""
         if denoise_length is None:
             mask = mask_split = None
         else:
@@ -244,10 +258,19 @@ class CrossAttnBlockApi(nn.Module):
         else:
             if self.self_attn_block_length == 2 and self.self_attn_combine_style == 'onebyone':
                 norm_q = self.norm_q(q)
-            norm_v = self.norm_v(v)
+            kv = None
+            if memory is not None:                                # ready since before the query chain got here
+                norm_v, kv, ready = memory
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ready)
+                norm_v.record_stream(cur)
+                if kv is not None:
+                    kv.record_stream(cur)
+            else:
+                norm_v = self.norm_v(v)
             feats = []
             if self.cross_attn is not None:
-                feats.append(self.cross_attn(norm_q, norm_v))
+                feats.append(self.cross_attn(norm_q, norm_v, kv=kv))
             if self.local_cross_attn is not None:
                 feats.append(self.local_cross_attn(q=norm_q, v=norm_v, q_pos=q_pos, v_pos=v_pos, idx=cross_attn_idx))
             if len(feats) != self.cross_attn_block_length:
@@ -310,12 +333,34 @@ class TransformerDecoder(nn.Module):
         self_attn_idx = knn_idx(self.k, q_pos, q_pos) if denoise_length is None else None
         cross_attn_idx = knn_idx(self.k, v_pos, q_pos)
         mask = None if denoise_length is None else CrossAttnBlockApi.denoise_mask(q.size(1), denoise_length, q.device)
+        # Inside a HIP-graph capture the memory side of every block (norm_v + the k / v projections: they depend on the
+        # encoder output only) becomes a parallel branch of the graph beside the query chain; each block joins through its
+        # own event.  In eager mode the same fork costs more in cross-stream events than it gains.
+        memory = [None] * len(self.blocks)
+        if OVERLAP_DECODER_MEMORY and v.is_cuda and torch.is_grad_enabled() and torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream()
+            side = _memory_streams.get(v.device.index)
+            if side is None:
+                side = _memory_streams[v.device.index] = torch.cuda.Stream(device=v.device)
+            side.wait_stream(cur)
+            v.record_stream(side)
+            with torch.cuda.stream(side):
+                for i, block in enumerate(self.blocks):
+                    m = block.memory_side(v, q.size(1))
+                    if m is not None:
+                        ready = torch.cuda.Event()
+                        ready.record(side)
+                        memory[i] = (m[0], m[1], ready)
+        else:
+            side = None
         normed = None
         for i, block in enumerate(self.blocks):
             nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
             out = block(q, v, q_pos, v_pos, self_attn_idx=self_attn_idx, cross_attn_idx=cross_attn_idx,
-                        denoise_length=denoise_length, denoise_mask=mask, normed=normed, next_norm=nxt)
+                        denoise_length=denoise_length, denoise_mask=mask, normed=normed, next_norm=nxt, memory=memory[i])
             q, normed = out if nxt is not None else (out, None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)      # every block joined through its event; this closes the fork
         return q
 
 
