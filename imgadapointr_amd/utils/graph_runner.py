@@ -333,6 +333,7 @@ class GraphedTrainStep:
         noise = static[-1] if has_noise else None
         self.step.zero_grad()
         graph = torch.cuda.CUDAGraph()
+        before = torch.cuda.current_stream(device)
         try:
             with state, torch.cuda.graph(graph), _native.capturing(state):
                 out = self.step(partial, gt, extra, epoch, noise,
@@ -340,7 +341,14 @@ class GraphedTrainStep:
         except torch.cuda.OutOfMemoryError:
             raise
         except (RuntimeError, TypeError) as exc:
-            torch.cuda.synchronize(device)
+            # `torch.cuda.graph.__exit__` does not restore the current stream when ending the capture raises: the eager
+            # fallback must not keep launching into the (invalidated) capture stream
+            torch.cuda.set_stream(before)
+            _log.warning("GraphedTrainStep: capture failed", exc_info=True)
+            try:
+                torch.cuda.synchronize(device)
+            except RuntimeError:
+                pass
             self.step.zero_grad()
             self._disable(f"capture failed: {type(exc).__name__}: {exc}")
             return None
