@@ -256,6 +256,24 @@ class PrivateState:
         self.tables = {n: {} for n in self._NAMES}
         self.keepalive = []            # pinned host tables, plans: whatever a captured node reads
         self._saved = None
+        # Pinned staging for the host tables a captured copy node reads (pointer tables, plans): allocated HERE, outside
+        # any capture - hipHostMalloc is not permitted while a stream of the process is capturing, and a flush whose queue
+        # differs from every warm-up flush would otherwise need a fresh pinned block in the middle of the capture.
+        self._pinned = torch.empty(8 << 20, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else None
+        self._pinned_used = 0
+
+    def pinned_copy(self, array):
+        """A pinned-memory copy of a numpy array (kept for the life of this object) -> uint8 tensor view of its bytes."""
+        import numpy as np
+        raw = np.ascontiguousarray(array).view(np.uint8).reshape(-1)
+        n = raw.size
+        start = (self._pinned_used + 63) & ~63
+        if self._pinned is None or start + n > self._pinned.numel():
+            raise PtopsError("private_state: pinned staging pool exhausted")
+        self._pinned_used = start + n
+        out = self._pinned[start:start + n]
+        out.numpy()[:] = raw
+        return out
 
     def __enter__(self):
         g = globals()
@@ -1076,11 +1094,9 @@ def wgrad_flush():
                 raise PtopsError("wgrad_flush: unsupported problem in the queue")
             host = np.zeros(need, dtype=np.uint8)
             lib.ptops_wgrad_group_plan(mnk.ctypes.data, flags.ctypes.data, n, 0, host.ctypes.data, need)
-            if _capture is not None:                          # a captured copy node: pinned source, kept alive
-                pinned = torch.from_numpy(host).pin_memory()
-                _capture.keepalive.append(pinned)
+            if _capture is not None:                          # a captured copy node: pinned source from the state's pool
                 dev_plan = torch.empty(need, dtype=torch.uint8, device=dev)
-                dev_plan.copy_(pinned, non_blocking=True)
+                dev_plan.copy_(_capture.pinned_copy(host), non_blocking=True)
             else:
                 dev_plan = torch.from_numpy(host).to(dev)
             plan = (host, dev_plan, int(lib.ptops_wgrad_group_workspace_bytes(host.ctypes.data)))
@@ -1111,10 +1127,10 @@ def wgrad_flush():
                 rows_dev = tables.pop(next(iter(tables)))       # its last readers)
             else:
                 rows_dev = torch.empty((n, 9), dtype=torch.int64, device=dev)
-            pinned = torch.from_numpy(rows).pin_memory()
-            rows_dev.copy_(pinned, non_blocking=True)
             if _capture is not None:                            # the copy node reads this table at every replay
-                _capture.keepalive.append(pinned)
+                rows_dev.copy_(_capture.pinned_copy(rows).view(torch.int64).view(n, 9), non_blocking=True)
+            else:
+                rows_dev.copy_(torch.from_numpy(rows).pin_memory(), non_blocking=True)
             tables[sig] = rows_dev
             wgrad_table_uploads[0] += 1
         if _capture is not None:
