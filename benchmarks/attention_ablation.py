@@ -3,6 +3,7 @@
 8 = no S^T MFMAs, 16 = no O^T MFMAs, 32 = no loads / staging after the first tile; results are wrong by construction) at the
 three training shapes (B = 32, 6 heads) and prints microseconds per launch.
 
+    make -C imgadapointr_amd/csrc clean && make -C imgadapointr_amd/csrc -j8 TUNING=1      # the variants are tuning-build only
     python benchmarks/attention_ablation.py
 """
 import os

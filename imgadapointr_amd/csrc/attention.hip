@@ -1449,11 +1449,13 @@ PTOPS_API int ptops_attention_forward(const float* q, const float* k, const floa
   // PTOPS_ATTN_FWD_F32=1 keeps the f32-MFMA kernel
   if (tiles >= 4 && !ptops::option("PTOPS_ATTN_FWD_F32")) {
     const dim3 grid(ptops::ceil_div(tiles, 4), B * H);
-    switch (ptops::option("PTOPS_ATTN_FWD_ABL")) {       // timing experiments (wrong results): see the kernel's header
+    switch (ptops::option("PTOPS_ATTN_FWD_ABL")) {
+#ifdef PTOPS_TUNING                                        // `make TUNING=1`: timing experiments (wrong results), see the kernel's header
 #define PTOPS_ABL_CASE(N) case N: hipLaunchKernelGGL(attn_fwd_split3_kernel<N>, grid, dim3(256), 0, stream, a); break;
       PTOPS_ABL_CASE(1) PTOPS_ABL_CASE(2) PTOPS_ABL_CASE(3) PTOPS_ABL_CASE(4) PTOPS_ABL_CASE(7) PTOPS_ABL_CASE(8)
       PTOPS_ABL_CASE(16) PTOPS_ABL_CASE(24) PTOPS_ABL_CASE(32) PTOPS_ABL_CASE(35) PTOPS_ABL_CASE(39) PTOPS_ABL_CASE(63)
 #undef PTOPS_ABL_CASE
+#endif
       default:
         if (ptops::option("PTOPS_ATTN_PRIO")) hipLaunchKernelGGL((attn_fwd_split3_kernel<0, true, true>), grid, dim3(256), 0, stream, a);
         else if (ptops::option("PTOPS_ATTN_STAGE_EARLY")) hipLaunchKernelGGL((attn_fwd_split3_kernel<0, false>), grid, dim3(256), 0, stream, a);
