@@ -256,11 +256,17 @@ class PrivateState:
         self.tables = {n: {} for n in self._NAMES}
         self.keepalive = []            # pinned host tables, plans: whatever a captured node reads
         self._saved = None
-        # Pinned staging for the host tables a captured copy node reads (pointer tables, plans): allocated HERE, outside
-        # any capture - hipHostMalloc is not permitted while a stream of the process is capturing, and a flush whose queue
-        # differs from every warm-up flush would otherwise need a fresh pinned block in the middle of the capture.
-        self._pinned = torch.empty(8 << 20, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else None
+        # Pinned staging for the host tables a captured copy node reads (pointer tables, plans): allocated by
+        # `new_pinned_pool()` BEFORE each capture - hipHostMalloc is not permitted while a stream of the process is
+        # capturing, and a flush whose queue differs from every warm-up flush would otherwise need a fresh pinned block in
+        # the middle of the capture.  One pool per capture: the graph's cache entry keeps it, an evicted graph frees it.
+        self._pinned = None
         self._pinned_used = 0
+
+    def new_pinned_pool(self, nbytes=1 << 20):
+        self._pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self._pinned_used = 0
+        return self._pinned
 
     def pinned_copy(self, array):
         """A pinned-memory copy of a numpy array (kept for the life of this object) -> uint8 tensor view of its bytes."""

@@ -324,6 +324,7 @@ class GraphedTrainStep:
             self._disable("the optimizer's fused clip + AdamW step does not support this parameter set")
             return None
         state = self._state
+        pinned = state.new_pinned_pool()       # host tables that captured copy nodes read live here, as long as the graph
         static = [t.clone() for t in tensors]
         partial, gt = static[0], static[1]
         extra = [None] * n_extra
@@ -352,7 +353,7 @@ class GraphedTrainStep:
             self.step.zero_grad()
             self._disable(f"capture failed: {type(exc).__name__}: {exc}")
             return None
-        return dict(static=static, graph=graph, out=out, plan=plan, state=state)
+        return dict(static=static, graph=graph, out=out, plan=plan, state=state, pinned=pinned)
 
     def _replay(self, entry, tensors):
         opt = self.step.optimizer
