@@ -325,6 +325,7 @@ class GraphedTrainStep:
             return None
         state = self._state
         pinned = state.new_pinned_pool()       # host tables that captured copy nodes read live here, as long as the graph
+        keep = state.keepalive = []            # ... and what else the capture asks to be kept (plans, replaced arenas)
         static = [t.clone() for t in tensors]
         partial, gt = static[0], static[1]
         extra = [None] * n_extra
@@ -353,7 +354,7 @@ class GraphedTrainStep:
             self.step.zero_grad()
             self._disable(f"capture failed: {type(exc).__name__}: {exc}")
             return None
-        return dict(static=static, graph=graph, out=out, plan=plan, state=state, pinned=pinned)
+        return dict(static=static, graph=graph, out=out, plan=plan, state=state, pinned=pinned, keep=keep)
 
     def _replay(self, entry, tensors):
         opt = self.step.optimizer
