@@ -230,3 +230,35 @@ def test_validate_and_metrics_match_the_reference(oracle_backend):
 def test_inference_cli_matches_the_reference(tmp_path, oracle_backend):
     import parity_checks as pc
     print(pc.check_inference("cpu", tmp_path))
+
+
+def test_graphed_train_step_falls_through_on_cpu_and_private_state_swaps_tables(oracle_backend):
+    """`GraphedTrainStep` on CPU tensors is the eager `TrainStep` (no GPU, nothing to capture), and `_native.private_state()`
+    swaps this module's workspace tables in and out without touching the global ones."""
+    from imgadapointr_amd import _native
+    from imgadapointr_amd.models import build_model_from_cfg
+    from imgadapointr_amd.tools import builder, runner
+    from imgadapointr_amd.utils.graph_runner import GraphedTrainStep
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    model = build_model_from_cfg(cfg.model).train()
+    step = GraphedTrainStep(runner.TrainStep(model, builder.build_optimizer(model, cfg)))
+    partial, gt = torch.rand(2, 256, 3) - 0.5, torch.rand(2, 512, 3) - 0.5
+    before = [p.detach().clone() for p in model.parameters()]
+    l0, l1 = step(partial, gt, (), 0)
+    assert torch.isfinite(l0) and torch.isfinite(l1) and step.replays == 0 and step.enabled
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))          # the eager step ran
+    assert step.optimizer is step.step.optimizer and step.ddp is None
+    marker = object()
+    _native._colsum_ws["marker"] = marker
+    try:
+        state = _native.private_state()
+        with state:
+            assert "marker" not in _native._colsum_ws
+            _native._colsum_ws["inside"] = 1
+        assert _native._colsum_ws.get("marker") is marker and "inside" not in _native._colsum_ws
+        assert state.tables["_colsum_ws"] == {"inside": 1}
+        with state:                                                   # the same tables come back on re-entry
+            assert _native._colsum_ws == {"inside": 1}
+    finally:
+        _native._colsum_ws.pop("marker", None)
