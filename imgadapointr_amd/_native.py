@@ -11,6 +11,7 @@ tests / the bench's cpu_baseline leg) may install a replacement backend object w
 `set_backend_for_testing`, e.g. one that routes to the CPU oracle to exercise the Python
 plumbing on a machine without a GPU; the package itself never imports the oracle.
 """
+import contextlib
 import ctypes
 import os
 
@@ -262,6 +263,28 @@ class PrivateState:
         # the middle of the capture.  One pool per capture: the graph's cache entry keeps it, an evicted graph frees it.
         self._pinned = None
         self._pinned_used = 0
+        self._wgrad_side = {}          # device index -> side stream of the weight-gradient branch (wgrad_flush)
+        self._wgrad_forked = None      # (backward stream, side stream) while flushes are outstanding on the branch
+
+    def fork_wgrad_branch(self, dev, queue):
+        """The side stream of the weight-gradient branch, made to wait for the work queued so far on the current (backward)
+        stream; the operands of `queue` are marked as used there."""
+        side = self._wgrad_side.get(dev.index)
+        if side is None:
+            side = self._wgrad_side[dev.index] = torch.cuda.Stream(device=dev)
+        main = _deferral_stream(dev)              # the stream the operands were produced on (not necessarily the caller's)
+        side.wait_stream(main)
+        for q in queue:
+            q[0].record_stream(side)
+            q[1].record_stream(side)
+        self._wgrad_forked = (main, side)
+        return side
+
+    def join_wgrad_branch(self):
+        if self._wgrad_forked is not None:
+            main, side = self._wgrad_forked
+            main.wait_stream(side)
+            self._wgrad_forked = None
 
     def new_pinned_pool(self, nbytes=1 << 20):
         self._pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
@@ -893,9 +916,19 @@ def fold_returning(*keys):
         _fold_seen.update(keys)
 
 
+def _deferral_stream(dev):
+    """The stream deferral is switched on for, as a torch stream object (the current stream outside `deferred_folds`)."""
+    if _fold_stream is None:
+        return torch.cuda.current_stream(dev)
+    return torch.cuda.ExternalStream(_fold_stream[1].value or 0, device=dev)
+
+
 def fold_flush():
-    """Runs the queued weight gradients and folds on the stream they were queued on (no-op when nothing is queued)."""
+    """Runs the queued weight gradients and folds on the stream they were queued on (no-op when nothing is queued).  A
+    caller on ANOTHER stream (a backward node of a side branch inside a graph capture) is made to wait for that stream: what
+    it asked for is visible to it when this returns."""
     wgrad_flush()
+    dev = None
     if _fold_keepalive:
         dev = _fold_keepalive[0].device
         with _on(dev):
@@ -904,6 +937,11 @@ def fold_flush():
         _fold_keepalive.clear()
         for slot in _fold_arena.values():               # stream order: the next producers write after this flush
             slot[1] = 0
+    if _fold_stream is not None:
+        dev = _fold_stream[0]
+        cur = torch.cuda.current_stream(dev)
+        if cur.cuda_stream != (_fold_stream[1].value or 0):
+            cur.wait_stream(_deferral_stream(dev))
 
 
 _fold_arena = {}              # device index -> [uint8 arena tensor, bump offset]
@@ -1075,12 +1113,28 @@ def wgrad_defer(dy, x, want_bias):
     # AccumulateGrad clone (= read) instead of adopting it
     _wgrad_queue.append((dy, x, dw.data_ptr(), db.data_ptr() if db is not None else 0, M, N, K, dw.untyped_storage(),
                          db.untyped_storage() if db is not None else None))
+    if _capture is not None and WGRAD_BRANCH_LAYERS > 0 and len(_wgrad_queue) >= WGRAD_BRANCH_LAYERS:
+        wgrad_flush(join=False)        # inside a graph capture: a parallel branch beside the rest of backward (see wgrad_flush)
     return dw, db
 
 
-def wgrad_flush():
-    """Runs every queued weight gradient in one grouped launch (csrc/gemm_split3.hip) on the deferral stream."""
+# Inside a HIP-graph capture the queued weight gradients do not wait for the end of backward: every WGRAD_BRANCH_LAYERS
+# layers the queue is launched on a side stream that forks from the backward stream at that point (two graph edges, not
+# cross-stream events), so the grouped weight-gradient launches run BESIDE the input-gradient chain instead of after it -
+# both families leave half of the matrix pipe idle on their own.  The branch joins where a result is needed
+# (`fold_flush`: the end of backward, or a gradient of unknown provenance).  0 = off.  Never used outside a capture: in
+# eager mode the same fork costs more in events than it gains.
+WGRAD_BRANCH_LAYERS = int(os.environ.get("PTOPS_WGRAD_BRANCH_LAYERS", "12"))
+
+
+def wgrad_flush(join=True):
+    """Runs every queued weight gradient in one grouped launch (csrc/gemm_split3.hip) on the deferral stream - or, inside a
+    graph capture with WGRAD_BRANCH_LAYERS > 0, on the capture's side stream; `join`: the deferral stream then waits for
+    that branch (everything flushed so far is visible to it afterwards)."""
+    branch = _capture is not None and WGRAD_BRANCH_LAYERS > 0
     if not _wgrad_queue:
+        if branch and join:
+            _capture.join_wgrad_branch()
         return
     import numpy as np
     queue = list(_wgrad_queue)
@@ -1088,8 +1142,12 @@ def wgrad_flush():
     dev = queue[0][0].device
     n = len(queue)
     lib = load()
-    with _on(dev):
-        handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(_current_stream(dev).cuda_stream)
+    side = _capture.fork_wgrad_branch(dev, queue) if branch else None
+    with _on(dev), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        if side is not None:
+            handle = ctypes.c_void_p(side.cuda_stream)
+        else:
+            handle = _fold_stream[1] if _fold_stream is not None else ctypes.c_void_p(_current_stream(dev).cuda_stream)
         key = (dev.index, tuple((q[4], q[5], q[6], q[3] != 0) for q in queue))
         plan = _wgrad_plans.get(key)
         if plan is None:
@@ -1144,6 +1202,8 @@ def wgrad_flush():
         _call("ptops_gemm_f32_split3_wgrad_grouped", ctypes.c_void_p(rows.ctypes.data), _ptr(rows_dev), n,
               ctypes.c_void_p(host_plan.ctypes.data), _ptr(dev_plan), _ptr(ws), ws.numel(), handle)
         # `queue` (operands, output storages) dies here: the launches are queued behind it in stream order
+    if branch and join:
+        _capture.join_wgrad_branch()
 
 
 def adamw_clip_step(rows_dev, n_tensors, chunks_dev, n_chunks, max_norm, beta1, beta2, eps, partial, norm_coef):
