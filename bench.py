@@ -229,14 +229,14 @@ class GemmProbe:
         # the grouped weight-gradient launch (all queued layers in one kernel + one reduction): its FLOPs are the queue's
         self.orig_flush = _native.wgrad_flush
 
-        def flush():
+        def flush(*a, **kw):
             if not (self.enabled and _native._wgrad_queue):
-                return self.orig_flush()
+                return self.orig_flush(*a, **kw)
             flops = sum(2.0 * q[4] * q[5] * q[6] for q in _native._wgrad_queue)
             n = len(_native._wgrad_queue)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self.orig_flush()
+            self.orig_flush(*a, **kw)
             e.record()
             self.rec.append(("gemm_split3_wgrad_grouped", s, e, flops))
             self.grouped_problems = n
