@@ -1122,9 +1122,12 @@ def wgrad_defer(dy, x, want_bias):
 # layers the queue is launched on a side stream that forks from the backward stream at that point (two graph edges, not
 # cross-stream events), so the grouped weight-gradient launches run BESIDE the input-gradient chain instead of after it -
 # both families leave half of the matrix pipe idle on their own.  The branch joins where a result is needed
-# (`fold_flush`: the end of backward, or a gradient of unknown provenance).  0 = off.  Never used outside a capture: in
-# eager mode the same fork costs more in events than it gains.
-WGRAD_BRANCH_LAYERS = int(os.environ.get("PTOPS_WGRAD_BRANCH_LAYERS", "12"))
+# (`fold_flush`: the end of backward, or a gradient of unknown provenance).  Never used outside a capture.
+# MEASURED SLOWER and therefore off (0) by default - in-process-equivalent A/B of graphed steps on one box, 12 layers per
+# launch vs one launch at the end: AdaPoinTr bs 32 31.5 vs 31.2 ms, image variant 24.4 vs 23.4, segmentation variant 33.8 vs
+# 33.0.  Two matrix-pipe kernels side by side share L2 delivery and the LDS, and eight small grouped launches lose the one
+# big launch's balance; the same verdict as the second-stream attempts of rounds 1-3, now without their event overhead.
+WGRAD_BRANCH_LAYERS = int(os.environ.get("PTOPS_WGRAD_BRANCH_LAYERS", "0"))
 
 
 def wgrad_flush(join=True):
