@@ -50,12 +50,14 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--marker", default="adamw_update_kernel", help="kernel launched a fixed number of times per step")
     ap.add_argument("--top", type=int, default=25)
+    ap.add_argument("--timeline", action="store_true",
+                    help="also: how much of the wall is covered by >= 1 / >= 2 kernels, the idle gaps, busy time per queue")
     a = ap.parse_args()
 
     rows = []
     with open(a.trace) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
     # markers per step: smallest period such that the kernel count between successive groups is constant
@@ -74,7 +76,7 @@ def main():
     wall = (rows[hi][0] - rows[lo][0]) / a.steps / 1e6
     fam_t, fam_n = collections.Counter(), collections.Counter()
     ker_t, ker_n = collections.Counter(), collections.Counter()
-    for s, e, n in win:
+    for s, e, n, _q in win:
         f = family(n)
         fam_t[f] += e - s
         fam_n[f] += 1
@@ -90,6 +92,46 @@ def main():
     print(f"\ntop {a.top} kernels")
     for k, t in ker_t.most_common(a.top):
         print(f"{t / a.steps / 1e6:9.3f} ms  x{ker_n[k] / a.steps:7.1f}  {k}")
+    if a.timeline:
+        timeline(win, rows[lo][0], rows[hi][0], a.steps)
+
+
+def timeline(win, t0, t1, steps):
+    """Coverage of the wall by running kernels: parallel graph branches show as time with >= 2 kernels in flight, launch
+    overhead as idle gaps between the end of one kernel and the start of the next."""
+    ev = []
+    for s, e, _n, _q in win:
+        ev.append((s, 1))
+        ev.append((e, -1))
+    ev.sort()
+    depth, last, cover = 0, t0, collections.Counter()
+    for t, d in ev:
+        cover[min(depth, 3)] += max(0, min(t, t1) - last)
+        last = max(last, min(t, t1))
+        depth += d
+    print("\ntimeline per step (ms): " + ", ".join(
+        f"{k if k < 3 else '>=3'} in flight {v / steps / 1e6:.2f}" for k, v in sorted(cover.items())))
+    # idle gaps: maximal intervals with nothing in flight
+    gaps, end = [], None
+    for s, e, n, _q in win:
+        if end is not None and s > end[0]:
+            gaps.append((s - end[0], end[1], n))
+        if end is None or e > end[0]:
+            end = (e, n)
+    buckets = collections.Counter()
+    for g, _a, _b in gaps:
+        key = "<2us" if g < 2000 else "2-5us" if g < 5000 else "5-20us" if g < 20000 else ">=20us"
+        buckets[key] += g
+        buckets[key + " n"] += 1
+    print("idle gaps per step: " + ", ".join(
+        f"{k}: {buckets[k] / steps / 1e6:.2f} ms in {buckets[k + ' n'] / steps:.0f}" for k in ("<2us", "2-5us", "5-20us", ">=20us")))
+    print("largest idle gaps (us, after -> before):")
+    for g, before, after in sorted(gaps, reverse=True)[:12]:
+        print(f"{g / 1e3:9.1f}  {re.sub(r'<.*', '', before)[:60]}  ->  {re.sub(r'<.*', '', after)[:60]}")
+    per_q = collections.Counter()
+    for s, e, _n, q in win:
+        per_q[q] += e - s
+    print("kernel time per queue (ms/step): " + ", ".join(f"{q or '?'}: {t / steps / 1e6:.2f}" for q, t in per_q.most_common()))
 
 
 if __name__ == "__main__":
