@@ -9,6 +9,7 @@ profiles/round4/timeline_graphed_img_r4_v1.txt), so the step is timed with parts
     no_img         image tokens are a constant: the encoder disappears completely
     no_seg         (seg only) GDANet part embeddings are a constant: normals + GDANet disappear
     no_img_no_seg  both
+    aten_topk      (seg only) GDANet's feature-space top-k on ATen instead of csrc/topk.hip
 
 `shipped - no_img` is the exposed cost of the image branch (0 = fully hidden), `serial - no_img` its serial cost.
 
@@ -25,6 +26,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from imgadapointr_amd.models import pctransformer  # noqa: E402
+from imgadapointr_amd.models.segmentation import GDANet_util  # noqa: E402
 from imgadapointr_amd.utils.graph_runner import GraphedTrainStep  # noqa: E402
 
 
@@ -59,8 +61,9 @@ def chain(*fs):
     return wrap
 
 
-def run(which, name, wrap, steps, overlap=True):
+def run(which, name, wrap, steps, overlap=True, native_topk=True):
     pctransformer.OVERLAP_IMAGE_BRANCH = overlap
+    GDANet_util.USE_NATIVE_TOPK = native_topk
     model, cfg, spec, step, batch, B = bench.make_workload(which, torch.device("cuda:0"), wrap=wrap)
     g = GraphedTrainStep(step, warmup=3, verify=False)
     s, _ = bench.time_steps(g, batch, steps, 3 + 1 + 3)
@@ -79,6 +82,7 @@ def main():
             run(which, "no_img_bwd", freeze_image_encoder, steps),
             run(which, "no_img", constant_tokens("_image_tokens"), steps)]
     if which == "seg":
+        rows.append(run(which, "aten_topk", None, steps, native_topk=False))
         rows.append(run(which, "no_seg", constant_tokens("_seg_tokens"), steps))
         rows.append(run(which, "no_img_no_seg", chain(constant_tokens("_image_tokens"), constant_tokens("_seg_tokens")), steps))
     rows.append(run(which, "shipped", None, steps))

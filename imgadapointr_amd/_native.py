@@ -48,6 +48,7 @@ def _declare(lib):
         "ptops_gather_forward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_gather_backward": (c_int, [P, P] + [c_int] * 4 + [P, P]),
         "ptops_knn": (c_int, [P, P] + [c_int] * 4 + [P, P]),
+        "ptops_topk_rows": (c_int, [P, ctypes.c_longlong, c_int, c_int, P, P]),
         "ptops_index_points_forward": (c_int, [P, P] + [c_int] * 5 + [P, P]),
         "ptops_index_points_backward": (c_int, [P, P] + [c_int] * 5 + [P, P]),
         "ptops_edge_group_forward": (c_int, [P, P, P] + [c_int] * 5 + [P, P]),
@@ -115,7 +116,7 @@ EXPORTS = (
     "ptops_chamfer_backward", "ptops_chamfer_backward_det_workspace_bytes", "ptops_chamfer_backward_det",
     "ptops_chamfer_reduce_workspace_bytes", "ptops_chamfer_reduce", "ptops_chamfer_reduce_backward",
     "ptops_furthest_point_sample",
-    "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_index_points_forward",
+    "ptops_gather_forward", "ptops_gather_backward", "ptops_knn", "ptops_topk_rows", "ptops_index_points_forward",
     "ptops_index_points_backward", "ptops_edge_group_forward", "ptops_edge_group_backward",
     "ptops_gather_max_forward", "ptops_gather_max_backward", "ptops_gather_max_act_forward", "ptops_gather_max_act_backward", "ptops_emd_forward", "ptops_emd_backward",
     "ptops_attention_forward", "ptops_attention_backward", "ptops_attention_backward_fused_workspace_bytes",
@@ -602,6 +603,22 @@ def knn(k, xyz, new_xyz):
     with _on(dev):
         idx = torch.empty((B, S, int(k)), dtype=torch.int32, device=dev)
         _call("ptops_knn", _ptr(xyz), _ptr(new_xyz), B, N, S, int(k), _ptr(idx), _stream(xyz))
+    return idx
+
+
+def topk_rows(x, k):
+    """x [...,N] float32 -> int64 [...,k]: the k largest per row by (value descending, column ascending);
+    `x.topk(k, dim=-1)[1]` with a defined order of equal values (GDANet's feature-space kNN)."""
+    if _test_backend is not None:
+        return _test_backend.topk_rows(x, k)
+    _check(x, "x", torch.float32, x.dim())
+    N = x.size(-1)
+    k = int(k)
+    if not (x.dim() >= 1 and 1 <= k <= N <= 2048):
+        raise ValueError(f"topk_rows: need 1 <= k <= N <= 2048, got k={k} for {tuple(x.shape)}")
+    with _on(x.device):
+        idx = torch.empty(tuple(x.shape[:-1]) + (k,), dtype=torch.int64, device=x.device)
+        _call("ptops_topk_rows", _ptr(x), x.numel() // N, N, k, _ptr(idx), _stream(x))
     return idx
 
 

@@ -128,6 +128,15 @@ int ptops_gather_backward(const float* grad_out, const int32_t* idx, int B, int 
 int ptops_knn(const float* xyz, const float* new_xyz, int B, int N, int S, int k,
               int32_t* idx, void* stream);
 
+/* Replaces the selection step of GDANet's feature-space kNN,
+ * `pairwise_distance.topk(k=k, dim=-1)[1]` (models/segmentation/GDANet_util.py:5-11;
+ * callers local_operator :14, local_operator_withnorm :40, GDM :73).
+ *   x [R,N] row-major -> idx [R,k] (int64): the k largest entries of each row,
+ *   ordered by (value descending, column ascending); -0 equals +0; NaN is not
+ *   supported.  Requires 1 <= k <= N <= 2048.                                   */
+int ptops_topk_rows(const float* x, long long R, int N, int k, long long* idx,
+                    void* stream);
+
 /* Replaces index_points (models/Transformer_utils.py:53-69) for idx [B,S,k]:
  *   out[b,s,j,:] = points[b, idx[b,s,j], :];  points [B,N,C] -> out [B,S,k,C].
  *   backward: grad_points [B,N,C] zeroed then scatter-added.                   */

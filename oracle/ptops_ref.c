@@ -250,6 +250,30 @@ REF_API void ref_square_distance(const float* src, const float* dst, int B, int 
  * (torch.topk largest=False, sorted=False — order unspecified in the reference).
  * Here the result is ordered by (distance, index) ascending, which also fixes the
  * membership on exact ties.                                                      */
+/* Row-wise top-k as GDANet's feature-space kNN uses it (reference models/segmentation/GDANet_util.py:5-11:
+ * `pairwise_distance.topk(k=k, dim=-1)[1]`): x [R,N] -> idx [R,k], the k largest entries of each row ordered by
+ * (value descending, column ascending).  torch.topk leaves the order of EQUAL values open; this is the order libptops
+ * defines (and any torch.topk result agrees with it wherever the values differ). */
+REF_API void ref_topk_rows(const float* x, long long R, int N, int k, long long* idx) {
+#pragma omp parallel for schedule(static)
+  for (long long r = 0; r < R; ++r) {
+    const float* xr = x + r * (long long)N;
+    long long* out = idx + r * (long long)k;
+    char* taken = (char*)calloc((size_t)N, 1);
+    for (int j = 0; j < k; ++j) {
+      /* the best column not yet taken: rows are short (<= 2048), a selection per round is enough */
+      int best = -1;
+      for (int c = 0; c < N; ++c) {
+        if (taken[c]) continue;
+        if (best < 0 || xr[c] > xr[best]) best = c;
+      }
+      taken[best] = 1;
+      out[j] = best;
+    }
+    free(taken);
+  }
+}
+
 REF_API void ref_knn(const float* xyz, const float* new_xyz, int B, int N, int S, int k,
                      int32_t* idx) {
 #pragma omp parallel for schedule(static)

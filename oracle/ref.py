@@ -147,6 +147,17 @@ def knn(k, xyz, new_xyz):
     return idx
 
 
+def topk_rows(x, k):
+    """x [...,N] -> int64 [...,k]: the k largest per row, ordered by (value descending, column ascending)."""
+    x = _f32(x)
+    N = x.shape[-1]
+    R = x.size // N
+    assert 1 <= k <= N
+    idx = np.empty(x.shape[:-1] + (int(k),), np.int64)
+    lib().ref_topk_rows(_fp(x), ctypes.c_longlong(R), N, int(k), idx.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    return idx
+
+
 def index_points_forward(points, idx):
     points, idx = _f32(points), _i32(idx)
     B, N, C = points.shape

@@ -38,6 +38,9 @@ class OracleBackend:
     def knn(self, k, xyz, new_xyz):
         return _pt(ref.knn(k, _np(xyz), _np(new_xyz)), xyz)
 
+    def topk_rows(self, x, k):
+        return torch.from_numpy(ref.topk_rows(_np(x), k)).to(x.device)
+
     def index_points_forward(self, points, idx):
         return _pt(ref.index_points_forward(_np(points), _np(idx)), points)
 

@@ -259,6 +259,41 @@ def test_knn_exact(native, ref, B, N, S, k, kind):
     assert np.array_equal(got, want)
 
 
+TOPK_CASES = [(16 * 512, 512, 30, "normal"), (2 * 512, 512, 64, "normal"), (64, 512, 512, "ties"), (300, 64, 64, "ties"),
+              (77, 100, 7, "normal"), (50, 2048, 130, "ties"), (33, 1000, 65, "normal"), (9, 1, 1, "normal"),
+              (40, 260, 1, "ties"), (21, 1023, 1023, "ties")]
+
+
+@pytest.mark.parametrize("R,N,k,kind", TOPK_CASES)
+def test_topk_rows_exact(native, ref, R, N, k, kind):
+    """csrc/topk.hip vs the oracle: indices bit for bit, ties included ((value desc, column asc)); on tie-free rows
+    that is torch.topk, which is what the reference calls (GDANet_util.py:5-11)."""
+    rng = np.random.default_rng(R + 3 * N + k)
+    x = rng.standard_normal((R, N)).astype(np.float32)
+    if kind == "ties":
+        x = (np.round(x * 2) / 2).astype(np.float32)
+        x[0, : min(N, 4)] = [0.0, -0.0, np.inf, -np.inf][: min(N, 4)]
+    got = native.topk_rows(_t(x), k)
+    assert got.dtype == torch.int64 and tuple(got.shape) == (R, k)
+    assert np.array_equal(got.cpu().numpy(), ref.topk_rows(x, k))
+    if kind == "normal":
+        assert torch.equal(got, _t(x).topk(k, dim=-1)[1])
+
+
+def test_topk_rows_unaligned_rows_and_batch_shape(native, ref):
+    rng = np.random.default_rng(11)
+    flat = _t(rng.standard_normal(1 + 6 * 40 * 512).astype(np.float32))
+    x = flat[1:].view(6, 40, 512)                         # 4-byte aligned only: the scalar-load variant
+    assert x.data_ptr() % 16 != 0 and x.is_contiguous()
+    got = native.topk_rows(x, 30)
+    assert tuple(got.shape) == (6, 40, 30)
+    assert np.array_equal(got.cpu().numpy(), ref.topk_rows(x.cpu().numpy(), 30))
+    with pytest.raises(ValueError):
+        native.topk_rows(x, 513)
+    with pytest.raises(ValueError):
+        native.topk_rows(x.transpose(1, 2), 3)
+
+
 def test_gather_and_grad(native, ref):
     rng = np.random.default_rng(3)
     feat = rng.standard_normal((3, 35, 2048)).astype(np.float32)

@@ -46,6 +46,24 @@ def test_knn_order_and_ties(ref):
         assert list(row) == order
 
 
+def test_topk_rows_is_torch_topk_with_a_defined_tie_order(ref):
+    """GDANet's feature-space kNN is `pairwise.topk(k, dim=-1)[1]` (reference GDANet_util.py:5-11): the restatement
+    returns torch.topk's indices wherever the values differ, and (value desc, column asc) among equal values."""
+    import torch
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 37, 512)).astype(np.float32)
+    for k in (1, 30, 64, 512):
+        assert np.array_equal(ref.topk_rows(x, k), torch.from_numpy(x).topk(k, dim=-1)[1].numpy())
+    y = (np.round(x * 3) / 3).astype(np.float32)          # many exact ties
+    y[0, 0, :5] = [0.0, -0.0, np.inf, -np.inf, 0.0]
+    idx = ref.topk_rows(y, 100)
+    val = np.take_along_axis(y, idx, -1)
+    assert np.array_equal(val, torch.from_numpy(y).topk(100, dim=-1)[0].numpy())      # the same multiset, sorted
+    step = np.diff(val, axis=-1)
+    assert (step <= 0).all() and (np.diff(idx, axis=-1)[step == 0] > 0).all()
+    assert idx[0, 0, 0] == 2 and idx.dtype == np.int64
+
+
 def test_chamfer_vs_float64_bruteforce(ref):
     rng = np.random.default_rng(1)
     a = (rng.random((3, 257, 3), dtype=np.float32) - 0.5)
