@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import GDANet_util as U
 from .GDANet_util import GDM, SGCAM, local_operator, local_operator_withnorm
 
 
@@ -43,21 +44,30 @@ class GDANet(nn.Module):
         self.SGCAM_1s, self.SGCAM_1g = SGCAM(64), SGCAM(64)
         self.SGCAM_2s, self.SGCAM_2g = SGCAM(64), SGCAM(64)
 
-    def _stage(self, feat, conv_a, conv_b, sharp, gentle, conv_merge):
-        f = F.relu(conv_b(F.relu(conv_a(feat)))).max(dim=-1, keepdim=False)[0]
+    @staticmethod
+    def _first_conv(x, k, conv_a, norm_plt=None):
+        """relu(conv_a(local_operator[_withnorm](x))): conv_a = Sequential(Conv2d 1x1, BatchNorm2d)."""
+        if U.FUSED_LOCAL_CONV:
+            extra = None if norm_plt is None else norm_plt.contiguous().view(x.size(0), -1, x.size(2))  # the raw view of :40-70
+            return F.relu(conv_a[1](U.local_conv(x, conv_a[0], k, extra)))
+        feat = local_operator(x, k=k) if norm_plt is None else local_operator_withnorm(x, norm_plt, k=k)
+        return F.relu(conv_a(feat))
+
+    def _stage(self, y, conv_b, sharp, gentle, conv_merge):
+        f = F.relu(conv_b(y)).max(dim=-1, keepdim=False)[0]
         fs, fg = GDM(f, M=512)
         f = torch.cat([sharp(f, fs.transpose(2, 1)), gentle(f, fg.transpose(2, 1))], 1)
         return F.relu(conv_merge(f))
 
     def forward(self, x, norm_plt, cls_label):
         B, C, N = x.size()
-        x1 = self._stage(local_operator_withnorm(x, norm_plt, k=30), self.conv1, self.conv11,
+        x1 = self._stage(self._first_conv(x, 30, self.conv1, norm_plt), self.conv11,
                          self.SGCAM_1s, self.SGCAM_1g, self.conv12)
         x1t = torch.cat((x, x1), dim=1)
-        x2 = self._stage(local_operator(x1t, k=30), self.conv2, self.conv21,
+        x2 = self._stage(self._first_conv(x1t, 30, self.conv2), self.conv21,
                          self.SGCAM_2s, self.SGCAM_2g, self.conv22)
         x2t = torch.cat((x1t, x2), dim=1)
-        x3 = F.relu(self.conv31(F.relu(self.conv3(local_operator(x2t, k=30))))).max(dim=-1, keepdim=False)[0]
+        x3 = F.relu(self.conv31(self._first_conv(x2t, 30, self.conv3))).max(dim=-1, keepdim=False)[0]
         x3 = F.relu(self.conv32(x3))
         xx = torch.cat((x1, x2, x3), dim=1)
 

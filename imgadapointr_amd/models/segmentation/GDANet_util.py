@@ -4,6 +4,8 @@ SGCAM :153-212.  The kNN here is in feature space (up to 131 channels), so the d
 matmul on PyTorch-ROCm; the clouds are the 512 coarse points, i.e. [B,512,512] matrices.
 The selection is libptops' row-wise top-k (csrc/topk.hip: one wavefront per row, 0.03 ms instead of 0.11-0.17 ms per call).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -56,6 +58,32 @@ def local_operator_withnorm(x, norm_plt, k, device=None):
     nbr = _gather_rows(xt, idx)
     nbr_norm = _gather_rows(nt, idx)
     return torch.cat((nbr - xt.unsqueeze(2), nbr, nbr_norm), dim=3).permute(0, 3, 1, 2)
+
+
+# True: the first 1x1 convolution of a local-operator stage is applied BEFORE the neighbour gather.  The stage input is
+# cat(nbr - centre, nbr[, nbr_normals]) over channels, so with W = [Wd | Wn | Wm] the convolution is
+#   y[:, n, j] = (Wd + Wn) x[idx[n, j]] + Wm normals[idx[n, j]] - Wd x[n] + b = P[idx[n, j]] + R[n]:
+# two Conv1d over the N points (P, R) and a gather of Co channels, instead of a Conv2d over N*k edges of 2C (+3) channels
+# - 15x fewer multiply-adds for k = 30, and the [B, 2C, N, k] edge tensor (257 MB for the 262-channel stage at B = 16), its
+# cat / permute copies and their backward are never built.  Same function; sums are associated differently (1e-6 relative).
+FUSED_LOCAL_CONV = os.environ.get("PTOPS_GDANET_FUSED_CONV", "1") != "0"
+
+
+def local_conv(x, conv, k, extra=None):
+    """`conv(local_operator(x, k))` - or, with `extra` = the normals as [B,3,N] channels, `conv(local_operator_withnorm(...))`
+    - for a 1x1 `nn.Conv2d`: x [B,C,N] -> [B,Co,N,k] (reference GDANet_util.py:14-70 followed by GDANet_ptseg.py:59,66,72)."""
+    B, C, N = x.shape
+    Co = conv.out_channels
+    idx, _ = knn(x, k=k)                                                 # [B,N,k] int64
+    W = conv.weight.view(Co, -1)
+    Wd = W[:, :C]
+    src, Wp = x, Wd + W[:, C:2 * C]
+    if extra is not None:
+        src, Wp = torch.cat((x, extra), dim=1), torch.cat((Wp, W[:, 2 * C:]), dim=1)
+    P = torch.nn.functional.conv1d(src, Wp.unsqueeze(-1))                # [B,Co,N]
+    R = torch.nn.functional.conv1d(x, -Wd.unsqueeze(-1), conv.bias)      # [B,Co,N]
+    g = torch.gather(P, 2, idx.view(B, 1, N * k).expand(-1, Co, -1))     # [B,Co,N*k]: P at every neighbour
+    return g.view(B, Co, N, k) + R.unsqueeze(-1)
 
 
 def GDM(x, M, device=None):

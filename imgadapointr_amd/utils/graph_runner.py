@@ -176,6 +176,9 @@ def memset_nodes_reliable(device):
     multi-block `sum(dim=1)`, whose semaphores are zeroed by a memset node."""
     key = (device.type, device.index)
     if key not in _memset_probe:
+        # the probe must not move the caller's random stream: it runs in front of the first capture of a process, i.e. between
+        # the jitter draw and the dropout masks of that train step (found as a 4e-4 loss difference against an eager run)
+        rng = torch.cuda.get_rng_state(device)
         with torch.cuda.device(device), torch.no_grad():
             x = torch.rand(1, 512, 1024, device=device)
             x.sum(dim=1)
@@ -194,6 +197,7 @@ def memset_nodes_reliable(device):
                 ok = ok and bool(torch.equal(out, want))
                 del scratch
             torch.cuda.synchronize(device)
+        torch.cuda.set_rng_state(rng, device)
         _memset_probe[key] = ok
     return _memset_probe[key]
 
@@ -404,7 +408,12 @@ class GraphedTrainStep:
                 self._disable("HIP-graph memset nodes do not replay reliably in this process (set "
                               "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first GPU call: imgadapointr_amd/__init__.py)")
                 return self.step(partial, gt, extra, epoch, denoise_noise)
+            # the captured step has not run: the random stream continues where the jitter left it, for the first replay as
+            # for the eager steps of the check below (a capture leaves the generator's eager-visible state alone on this
+            # stack - benchmarks/probes/rng_after_graph_probe.py - this makes it independent of that)
+            rng = torch.cuda.get_rng_state(device)
             entry = self._capture(tensors, epoch, has_noise, len(extra), slots)
+            torch.cuda.set_rng_state(rng, device)
             if entry is None:
                 return self.step(partial, gt, extra, epoch, denoise_noise)
             if self.verify:

@@ -175,3 +175,36 @@ def test_attention_backward_switch_is_parsed_not_truthy():
     assert _parse_attn_bwd("0") is False and _parse_attn_bwd("false") is False and _parse_attn_bwd("off") is False
     with pytest.raises(ValueError):
         _parse_attn_bwd("spilt")
+
+
+def test_gdanet_local_conv_before_the_gather_is_the_same_function():
+    """GDANet's local-operator stages (reference GDANet_util.py:14-70 + GDANet_ptseg.py:59,66,72) with the first 1x1
+    convolution applied before the neighbour gather (`GDANet_util.local_conv`) against the literal edge-tensor form, in
+    float64, train mode (batch statistics): embeddings, log-probabilities, input gradient and running statistics."""
+    import torch
+    from imgadapointr_amd.models.segmentation import GDANet_util as U
+    from imgadapointr_amd.models.segmentation.GDANet_ptseg import GDANet
+    torch.manual_seed(0)
+    m = GDANet(50).double().train()
+    B, N = 2, 512
+    x = torch.rand(B, 3, N, dtype=torch.double) - 0.5
+    normals = torch.nn.functional.normalize(torch.randn(B, N, 3, dtype=torch.double), dim=-1)
+    cls = torch.zeros(B, 16, dtype=torch.double)
+    cls[:, 3] = 1
+    results = []
+    was = U.FUSED_LOCAL_CONV
+    try:
+        for fused in (False, True):
+            U.FUSED_LOCAL_CONV = fused
+            torch.manual_seed(1)                                  # the two dropout masks
+            for b in m.modules():
+                if isinstance(b, torch.nn.modules.batchnorm._BatchNorm):
+                    b.reset_running_stats()
+            xx = x.clone().requires_grad_(True)
+            emb, logp = m(xx, normals, cls)
+            (emb.square().sum() + logp.sum()).backward()
+            results.append((emb.detach(), logp.detach(), xx.grad.clone(), m.bn3.running_var.clone(), m.bn1.running_mean.clone()))
+    finally:
+        U.FUSED_LOCAL_CONV = was
+    for lit, fus in zip(*results):
+        assert (lit - fus).abs().max() <= 1e-10 * max(1.0, float(lit.abs().max()))

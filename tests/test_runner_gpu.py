@@ -337,7 +337,8 @@ def test_graphed_train_step_equals_eager(native, case):
     else:
         # seg: GDANet in train mode over B = 2 (feature-space top-k at near-ties, a max-pool backward without a deterministic
         # form) amplifies rounding-level differences over the steps (its arms differ from each other by
-        # percents in the gradient), and its branch runs beside the decoder inside the graph; 3e-4 was seen at step 6
+        # percents in the gradient), and its branch runs beside the decoder inside the graph; 3e-4 (literal local operator) and
+        # 1.4e-2 (first convolution before the gather) were seen at steps 5-6
         tol = 1e-3 if case == "seg" else 1e-4
         if case == "segenc":
             # segmentation BEFORE the encoder output: GDANet's dropout draws from the generator before the denoise jitter
@@ -345,8 +346,16 @@ def test_graphed_train_step_equals_eager(native, case):
             # numbers, so only the capture-time check (same numbers handed to both) and the size of the losses are compared
             tol = 0.25
             assert all(v <= 1e-2 for v in graph_step.verified["replay_vs_eager"].values()), graph_step.verified
-        for (a0, a1), (b0, b1) in zip(le, lg):
-            assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (le, lg)
+        rel = [max(abs(a0 - b0) / abs(a0), abs(a1 - b1) / abs(a1)) for (a0, a1), (b0, b1) in zip(le, lg)]
+        print(case, "per-step relative loss difference:", ["%.1e" % r for r in rel])
+        for i, r in enumerate(rel):
+            # seg: steps 0-3 are eager steps in both runs (the fourth is the capture's checked eager step) and must agree like
+            # two eager runs do - bit for bit under the pinned library choices; this is what caught the memset probe of
+            # utils/graph_runner.py drawing random numbers between the jitter and GDANet's dropout masks.  Step 4 is the first
+            # replay, from an identical state.  Afterwards the two trajectories are two samples of a chaotic map (a replayed
+            # update differs from the eager one at the 1e-6 level and GDANet's neighbour sets flip on that: 1e-2 by step 5-6)
+            limit = tol if case != "seg" else (1e-6 if i <= 3 else 1e-4 if i == 4 else 5e-2)
+            assert r <= limit, (i, rel, le, lg)
         lr = 1e-4
         far = sum(int(((pe[n] - pg[n]).abs() > 0.5 * lr).sum()) for n in pe)
         assert case == "segenc" or far <= 0.02 * sum(p.numel() for p in pe.values()), far
