@@ -44,7 +44,8 @@ def main():
     write = (m.get("WRITE_SIZE", 0.0) + p.get("WRITE_SIZE", 0.0)) * 1024
     cycles = m["GRBM_GUI_ACTIVE"] / 8.0
     out = {
-        "kernel": "chamfer_prep_kernel + chamfer_mfma_kernel (B=32, n=m=16384, one launch each = both directions)",
+        "kernel": ("chamfer_prep_kernel + chamfer_mfma_kernel" if p else "chamfer_mfma_kernel (coordinates split in the kernel: no prep pass)")
+                  + " (B=32, n=m=16384, one launch = both directions)",
         "command": "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python3 benchmarks/chamfer_only.py 4 16384 16384 mfma "
                    "(one pass per counter group: SQ/GRBM, FETCH_SIZE, WRITE_SIZE)",
         "avg_duration_us_under_pmc": dur_us,
@@ -53,9 +54,11 @@ def main():
             "fetch_bytes_raw": fetch, "fetch_bytes_gfx950_corrected_x2": 2 * fetch, "write_bytes": write,
             "hbm_traffic_bytes_corrected": 2 * fetch + write,
             "algorithmic_bytes": 20.0 * B * 2 * n,
-            "note_traffic": "prep + search kernels together.  The prep pass writes 48 bytes of bf16 operand pieces per "
-                            "candidate (50 MB for both clouds) and the search reads them back through L2 (each XCD holds the "
-                            "clouds its workgroups work on); dist/idx are 8.4 MB.",
+            "note_traffic": ("prep + search kernels together.  The prep pass writes 48 bytes of bf16 operand pieces per "
+                             "candidate (50 MB for both clouds) and the search reads them back through L2 (each XCD holds the "
+                             "clouds its workgroups work on); dist/idx are 8.4 MB.") if p else
+                            ("search kernel alone: it reads 12 bytes per candidate per (cloud, query tile) through its XCD's L2 and "
+                             "splits them itself; dist/idx are 8.4 MB."),
             "mfma_instructions": pairs / 1024 * 2,
             "mfma_busy_fraction": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024),
             "valu_busy_fraction": m["SQ_ACTIVE_INST_VALU"] * 4 / (cycles * 1024),

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void chamfer_mfma_unpack_kernel(const unsigned
 }
 
 // (kTPB, 4): at most 128 registers (4 workgroups per CU); it also makes hipcc write MFMA results to VGPRs.
-template <bool PREFETCH>
+// INLINE: no prep pass - thread t of the workgroup owns candidate t of a 256-candidate tile: it fetches the three
+// coordinates (12 bytes instead of the 48 of a pre-split row), keeps them in three registers under the tile's math and splits
+// them into the three operand entries right before the LDS store.  The entries are bit for bit those of chamfer_prep_kernel.
+template <bool PREFETCH, bool INLINE>
 __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
   __shared__ uint4 tile[2][kEntT];   // two tiles of A operand entries, 12 KB each
 
@@ -214,9 +217,32 @@ __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const uint4 zero_u4 = make_uint4(0u, 0u, 0u, 0u);
-  // thread t stages entries t, t + 256 and t + 512 of a tile
-  const uint4* __restrict__ gp = pptr + (size_t)b * (ncp / kBlk * kEntB) + (size_t)tl_begin * kEntT + threadIdx.x;
-  {
+  // thread t stages entries t, t + 256 and t + 512 of a tile (INLINE: the three k-group entries of candidate t of the tile)
+  const uint4* __restrict__ gp = INLINE ? nullptr : pptr + (size_t)b * (ncp / kBlk * kEntB) + (size_t)tl_begin * kEntT + threadIdx.x;
+  // INLINE: candidate t of a tile sits in block t / 32, row t % 32: entries (t / 32) * 96 + kg * 32 + t % 32
+  const int own = (threadIdx.x >> 5) * kEntB + (threadIdx.x & 31);
+  auto fetch_xyz = [&](int tl, float& x, float& y, float& z) {
+    const int j = tl * kTileC + threadIdx.x;
+    const int jj = j < nc ? j : 0;
+    x = cb[(size_t)jj * 3 + 0];
+    y = cb[(size_t)jj * 3 + 1];
+    z = cb[(size_t)jj * 3 + 2];
+  };
+  auto split_store = [&](int buf, int tl, float x, float y, float z) {
+    const bool pad = tl * kTileC + (int)threadIdx.x >= nc;
+    if (pad) x = y = z = 0.f;
+    const float w = pad ? kBig : __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+    const Split3 sn = split3(w);
+    const __bf16 zero = (__bf16)0.0f;
+    tile[buf][own] = __builtin_bit_cast(uint4, cand_operand(split3(-2.0f * x), sn.h, sn.m));
+    tile[buf][own + 32] = __builtin_bit_cast(uint4, cand_operand(split3(-2.0f * y), sn.l, zero));
+    tile[buf][own + 64] = __builtin_bit_cast(uint4, cand_operand(split3(-2.0f * z), zero, zero));
+  };
+  if (INLINE) {
+    float x, y, z;
+    fetch_xyz(tl_begin, x, y, z);
+    split_store(0, tl_begin, x, y, z);
+  } else {
     const uint4 e0 = gp[0], e1 = gp[256], e2 = gp[512];
     tile[0][threadIdx.x] = e0;
     tile[0][threadIdx.x + 256] = e1;
@@ -227,11 +253,16 @@ __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
     const int cur = (tl - tl_begin) & 1;
     const bool more = tl + 1 < tl_end;
     uint4 e0 = zero_u4, e1 = zero_u4, e2 = zero_u4;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
     if (more) {                                       // next tile: global -> registers now, -> LDS after the math
-      gp += kEntT;
-      e0 = gp[0];
-      e1 = gp[256];
-      e2 = gp[512];
+      if (INLINE) {
+        fetch_xyz(tl + 1, nx, ny, nz);
+      } else {
+        gp += kEntT;
+        e0 = gp[0];
+        e1 = gp[256];
+        e2 = gp[512];
+      }
     }
     if (PREFETCH) {
       // The same work with the fragments of the NEXT block pair requested right behind the MFMAs of the current one, so
@@ -366,9 +397,13 @@ __global__ __launch_bounds__(kTPB, 4) void chamfer_mfma_kernel(ArgsM a) {
       }
     }
     if (more) {
-      tile[cur ^ 1][threadIdx.x] = e0;
-      tile[cur ^ 1][threadIdx.x + 256] = e1;
-      tile[cur ^ 1][threadIdx.x + 512] = e2;
+      if (INLINE) {
+        split_store(cur ^ 1, tl + 1, nx, ny, nz);
+      } else {
+        tile[cur ^ 1][threadIdx.x] = e0;
+        tile[cur ^ 1][threadIdx.x + 256] = e1;
+        tile[cur ^ 1][threadIdx.x + 512] = e2;
+      }
     }
     __syncthreads();
   }
@@ -558,7 +593,11 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   unsigned long long* packed = (unsigned long long*)w;
 
   const PlanM p = make_plan(B, n, m);
-  {  // direction 0 searches cloud 2, direction 1 searches cloud 1: operands of the clouds that are searched, one launch
+  // PTOPS_CHAMFER_MFMA_PREP=1: the round-2 form with the candidates pre-split by a pass of their own (50 MB written and read
+  // back per 16384 x 16384 x 32 launch); default: the search kernel splits the coordinates itself
+  const bool inline_split = !ptops::option("PTOPS_CHAMFER_MFMA_PREP") && !ptops::option("PTOPS_CHAMFER_MFMA_PREFETCH");
+  int rc = PTOPS_OK;
+  if (!inline_split) {  // direction 0 searches cloud 2, direction 1 searches cloud 1: operands of the clouds that are searched, one launch
     PrepArgs pa;
     pa.xyz[0] = xyz1, pa.xyz[1] = xyz2;
     pa.prep[0] = on[1] ? prep1 : nullptr, pa.prep[1] = on[0] ? prep2 : nullptr;
@@ -567,9 +606,9 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
     const size_t e0 = on[1] ? padsb(n) / kBlk * kEntB : 0, e1 = on[0] ? padsb(m) / kBlk * kEntB : 0;
     const size_t emax = e0 > e1 ? e0 : e1;
     hipLaunchKernelGGL(chamfer_prep_kernel, dim3((unsigned)((emax + 255) / 256), B, 2), dim3(256), 0, stream, pa);
+    rc = ptops::check_launch("chamfer_prep_kernel");
+    if (rc != PTOPS_OK) return rc;
   }
-  int rc = ptops::check_launch("chamfer_prep_kernel");
-  if (rc != PTOPS_OK) return rc;
   const bool split[2] = {on[0] && p.splits[0] > 1, on[1] && p.splits[1] > 1};
   if (split[0]) (void)ptops::fill_async(packed, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream);
   if (split[1]) (void)ptops::fill_async(packed + (size_t)B * n, 0xFF, sizeof(unsigned long long) * (size_t)B * m, stream);
@@ -590,9 +629,11 @@ int forward(const float* xyz1, const float* xyz2, int B, int n, int m, float* di
   // 1.62 vs 0.94 ms, profiles/round3/chamfer_mfma_ab_v1.log): the second fragment set does not fit the 128 registers
   // of four workgroups per CU and hipcc spills inside the loop; kept switchable for the record.
   if (ptops::option("PTOPS_CHAMFER_MFMA_PREFETCH"))
-    hipLaunchKernelGGL(chamfer_mfma_kernel<true>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+    hipLaunchKernelGGL((chamfer_mfma_kernel<true, false>), dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+  else if (inline_split)
+    hipLaunchKernelGGL((chamfer_mfma_kernel<false, true>), dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
   else
-    hipLaunchKernelGGL(chamfer_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
+    hipLaunchKernelGGL((chamfer_mfma_kernel<false, false>), dim3((unsigned)blocks), dim3(kTPB), 0, stream, a);
   rc = ptops::check_launch("chamfer_mfma_kernel");
   if (rc != PTOPS_OK) return rc;
   for (int d = 0; d < 2; ++d) {

@@ -58,7 +58,7 @@ struct Option {
   int value;
 };
 Option g_options[] = {{"PTOPS_ATTN_FWD_F32", 0},  {"PTOPS_ATTN_BWD_F32", 0}, {"PTOPS_ATTN_FWD_WAVES", 0},
-                      {"PTOPS_ATTN_DKV_WAVES", 0}, {"PTOPS_ATTN_FWD_ABL", 0}, {"PTOPS_ATTN_STAGE_EARLY", 0}, {"PTOPS_ATTN_PRIO", 0}, {"PTOPS_ATTN_QSPLIT", 0}, {"PTOPS_ATTN_NO_XCD_REMAP", 0}, {"PTOPS_CHAMFER_MFMA_PREFETCH", 0}, {"PTOPS_GEMM_OCC3", 0},
+                      {"PTOPS_ATTN_DKV_WAVES", 0}, {"PTOPS_ATTN_FWD_ABL", 0}, {"PTOPS_ATTN_STAGE_EARLY", 0}, {"PTOPS_ATTN_PRIO", 0}, {"PTOPS_ATTN_QSPLIT", 0}, {"PTOPS_ATTN_NO_XCD_REMAP", 0}, {"PTOPS_CHAMFER_MFMA_PREFETCH", 0}, {"PTOPS_CHAMFER_MFMA_PREP", 0}, {"PTOPS_GEMM_OCC3", 0},
                       {"PTOPS_WGRAD_GROUP_STEPS", 0}, {"PTOPS_WGRAD_OCC3", 0}, {"PTOPS_GEMM_DEBUG_NO_STORE", 0}};
 std::once_flag g_options_once;
 void read_options() {
