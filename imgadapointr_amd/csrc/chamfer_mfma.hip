@@ -5,8 +5,9 @@
 //
 // The brute-force kernel is at the VALU issue ceiling: the reference's arithmetic costs 6.8 vector instructions per
 // pair.  Here the matrix pipe does the searching and the vector pipe only the bookkeeping:
-//   * every coordinate is split into three bf16 pieces (x = h + m + l, exact to 2^-27); a prep pass turns candidate c
-//     into one row of an MFMA A operand holding the pieces of -2c and of |c|^2, a query q is one column of the B
+//   * every coordinate is split into three bf16 pieces (x = h + m + l, exact to 2^-27); candidate c becomes one row of
+//     an MFMA A operand holding the pieces of -2c and of |c|^2 (built by the search kernel itself while it stages a tile;
+//     until late round 4 by a prep pass, kept behind PTOPS_CHAMFER_MFMA_PREP=1), a query q is one column of the B
 //     operand holding its pieces and ones, arranged so that 21 k-slots sum every piece product down to
 //     2^-18 |c||q|:  D[c][q] = |c|^2 - 2 c.q = |c - q|^2 - |q|^2 (products of bf16 pieces are exact in f32, the
 //     accumulation is f32) at 16 pairs per cycle and SIMD on the matrix pipe, against 4.7 for the VALU kernel;
