@@ -209,19 +209,23 @@ def test_fast_paths_single_step_all_gradients(native):
     assert abs(fa[0] - fb[0]) < 2e-5 * abs(fb[0]) and abs(fa[1] - fb[1]) < 2e-5 * abs(fb[1]), (fa, fb)
     assert set(ga) == set(gb) and len(ga) == 332 - 8          # 335 state-dict tensors - 3 BatchNorm buffers - 8 unused
     total = sum(float(v.double().pow(2).sum()) for v in gb.values()) ** 0.5
-    worst, n_checked = ("", 0.0), 0
+    rel, sq_err = {}, 0.0
     for n in gb:
         ref_norm = float(gb[n].double().norm())
         err = float((ga[n].double() - gb[n].double()).norm())
+        sq_err += err * err
         if ref_norm < 1e-5 * total:                     # gradients that are zero in exact arithmetic (k_map biases ...)
             assert float(ga[n].double().norm()) < 1e-4 * total, n
             continue
-        n_checked += 1
-        if err / ref_norm > worst[1]:
-            worst = (n, err / ref_norm)
+        rel[n] = err / ref_norm
+    worst = max(rel.items(), key=lambda kv: kv[1])
+    over = sorted(((v, n) for n, v in rel.items() if v >= 2e-2), reverse=True)
     # rounding-level differences flip a few arg-maxes (max-pools, kNN-free top-k of the query ranking), which moves single
-    # tensors by up to ~1 % (tests/parity_checks.py); a wrong kernel moves its tensor by O(1)
-    assert n_checked >= 280 and worst[1] < 2e-2, (worst, n_checked)
+    # tensors by ~1 % (tests/parity_checks.py) and once in eight boxes of the pool one of them past 2 %; a wrong kernel moves
+    # ITS tensors by O(1) and the whole gradient with them: at most three tensors may pass 2 %, none 15 %, and the error of
+    # the whole gradient vector stays below 2.5 % (0.7 % on a typical box, worst tensor 1.6 %)
+    assert len(rel) >= 280 and len(over) <= 3 and worst[1] < 0.15 and sq_err ** 0.5 < 2.5e-2 * total, \
+        (worst, over[:6], sq_err ** 0.5 / total, len(rel))
     lr = 1e-4
     far = n_el = 0
     for n in pb:
@@ -233,7 +237,7 @@ def test_fast_paths_single_step_all_gradients(native):
         n_el += d.numel()
         assert float(d.max()) <= 2.2 * lr, (n, float(d.max()))
     assert far <= 0.03 * n_el, (far, n_el)              # first AdamW step = lr * sign(g): only near-zero gradients differ
-    print("worst gradient tensor", worst, "elements off after the update", far / n_el)
+    print("worst gradient tensor", worst, "whole-gradient error", sq_err ** 0.5 / total, "elements off after the update", far / n_el)
 
 
 @pytest.mark.gpu
