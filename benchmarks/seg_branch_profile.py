@@ -36,13 +36,16 @@ def main():
         for _ in range(3):
             once()
         torch.cuda.synchronize()
+    from torch.autograd import DeviceType
     rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
-    total = sum(e.self_device_time_total for e in rows) / 3
-    print(f"device time {total / 1e3:.3f} ms per call, {sum(e.count for e in rows) / 3:.0f} device ops per call")
-    rows.sort(key=lambda e: -e.self_device_time_total)
-    for e in rows[:45]:
-        shapes = str(e.input_shapes)[:90] if e.input_shapes else ""
-        print(f"{e.self_device_time_total / 3 / 1e3:8.3f} ms  x{e.count / 3:6.1f}  {e.key[:70]:70s} {shapes}")
+    for title, keep in (("operators (device time of the kernels they launch)", lambda e: e.device_type == DeviceType.CPU),
+                        ("kernels", lambda e: e.device_type != DeviceType.CPU)):
+        part = sorted((e for e in rows if keep(e)), key=lambda e: -e.self_device_time_total)
+        total = sum(e.self_device_time_total for e in part) / 3
+        print(f"\n{title}: {total / 1e3:.3f} ms per call, {sum(e.count for e in part) / 3:.0f} per call")
+        for e in part[:32]:
+            shapes = str(e.input_shapes)[:90] if e.input_shapes else ""
+            print(f"{e.self_device_time_total / 3 / 1e3:8.3f} ms  x{e.count / 3:6.1f}  {e.key[:70]:70s} {shapes}")
 
 
 if __name__ == "__main__":

@@ -69,6 +69,19 @@ def local_operator_withnorm(x, norm_plt, k, device=None):
 FUSED_LOCAL_CONV = os.environ.get("PTOPS_GDANET_FUSED_CONV", "1") != "0"
 
 
+class _ContiguousGrad(torch.autograd.Function):
+    """Identity whose gradient is made contiguous: the gradient of `local_conv`'s output arrives channel-major (it is the
+    backward of a permute), and a scatter-add reading it token-major with a 61 KB stride between channels ran 11x slower."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 def local_conv(x, conv, k, extra=None):
     """`conv(local_operator(x, k))` - or, with `extra` = the normals as [B,3,N] channels, `conv(local_operator_withnorm(...))`
     - for a 1x1 `nn.Conv2d`: x [B,C,N] -> [B,Co,N,k] (reference GDANet_util.py:14-70 followed by GDANet_ptseg.py:59,66,72)."""
@@ -82,8 +95,11 @@ def local_conv(x, conv, k, extra=None):
         src, Wp = torch.cat((x, extra), dim=1), torch.cat((Wp, W[:, 2 * C:]), dim=1)
     P = torch.nn.functional.conv1d(src, Wp.unsqueeze(-1))                # [B,Co,N]
     R = torch.nn.functional.conv1d(x, -Wd.unsqueeze(-1), conv.bias)      # [B,Co,N]
-    g = torch.gather(P, 2, idx.view(B, 1, N * k).expand(-1, Co, -1))     # [B,Co,N*k]: P at every neighbour
-    return g.view(B, Co, N, k) + R.unsqueeze(-1)
+    # the gather runs token-major (a neighbour = one row of Co contiguous channels): its backward is a scatter-add whose
+    # consecutive threads hit consecutive channels of ONE destination row (0.17 ms) instead of 30-fold contended scalar atomics
+    # all over a channel's 512 points (0.74 ms for the 128-channel stage when gathered channel-major)
+    y = _ContiguousGrad.apply(_gather_rows(P.transpose(2, 1).contiguous(), idx)) + R.transpose(2, 1).unsqueeze(2)   # [B,N,k,Co]
+    return y.permute(0, 3, 1, 2).contiguous()
 
 
 def GDM(x, M, device=None):
