@@ -11,6 +11,7 @@ profiles/round4/timeline_graphed_img_r4_v1.txt), so the step is timed with parts
     no_img_no_seg  both
     aten_topk      (seg only) GDANet's feature-space top-k on ATen instead of csrc/topk.hip
     literal_conv   (seg only) GDANet's local-operator stages as the reference writes them (edge tensor + Conv2d)
+    nchw_stage     (seg only) first conv before the gather, but BatchNorm / ReLU / conv / max on ATen + MIOpen in NCHW
 
 `shipped - no_img` is the exposed cost of the image branch (0 = fully hidden), `serial - no_img` its serial cost.
 
@@ -62,10 +63,11 @@ def chain(*fs):
     return wrap
 
 
-def run(which, name, wrap, steps, overlap=True, native_topk=True, fused_conv=True):
+def run(which, name, wrap, steps, overlap=True, native_topk=True, fused_conv=True, token_major=True):
     pctransformer.OVERLAP_IMAGE_BRANCH = overlap
     GDANet_util.USE_NATIVE_TOPK = native_topk
     GDANet_util.FUSED_LOCAL_CONV = fused_conv
+    GDANet_util.TOKEN_MAJOR_STAGE = token_major
     model, cfg, spec, step, batch, B = bench.make_workload(which, torch.device("cuda:0"), wrap=wrap)
     g = GraphedTrainStep(step, warmup=3, verify=False)
     s, _ = bench.time_steps(g, batch, steps, 3 + 1 + 3)
@@ -86,6 +88,7 @@ def main():
     if which == "seg":
         rows.append(run(which, "aten_topk", None, steps, native_topk=False))
         rows.append(run(which, "literal_conv", None, steps, fused_conv=False))
+        rows.append(run(which, "nchw_stage", None, steps, token_major=False))
         rows.append(run(which, "no_seg", constant_tokens("_seg_tokens"), steps))
         rows.append(run(which, "no_img_no_seg", chain(constant_tokens("_image_tokens"), constant_tokens("_seg_tokens")), steps))
     rows.append(run(which, "shipped", None, steps))

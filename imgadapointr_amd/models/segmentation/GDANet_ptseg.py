@@ -53,22 +53,38 @@ class GDANet(nn.Module):
         feat = local_operator(x, k=k) if norm_plt is None else local_operator_withnorm(x, norm_plt, k=k)
         return F.relu(conv_a(feat))
 
-    def _stage(self, y, conv_b, sharp, gentle, conv_merge):
-        f = F.relu(conv_b(y)).max(dim=-1, keepdim=False)[0]
+    def _edge_stage(self, x, k, conv_a, conv_b, norm_plt=None):
+        """relu(conv_b(relu(conv_a(local_operator[_withnorm](x))))).max over the k neighbours: x [B,C,N] -> [B,Co,N]."""
+        if (U.TOKEN_MAJOR_STAGE and U.FUSED_LOCAL_CONV and self.training and x.is_cuda and x.dtype == torch.float32
+                and torch.is_grad_enabled() and U._native.backend_for_testing() is None
+                and conv_a[0].out_channels % 4 == 0 and conv_b[0].out_channels % 4 == 0):
+            from ..AdaPoinTr import _BatchNormRowsLeakyReLU, _linear_tokens
+            from ..Transformer_utils import max_over_tokens
+            B, _, N = x.shape
+            extra = None if norm_plt is None else norm_plt.contiguous().view(B, -1, N)
+            y = U.local_conv(x, conv_a[0], k, extra, token_major=True)                    # [B,N,k,Ca]
+            bn_a, bn_b, lin = conv_a[1], conv_b[1], conv_b[0]
+            a = _BatchNormRowsLeakyReLU.apply(y.view(-1, y.size(-1)), bn_a.weight, bn_a.bias, bn_a, 0.0)   # slope 0: ReLU
+            b = _linear_tokens(a, lin.weight.view(lin.out_channels, -1), lin.bias)
+            c = _BatchNormRowsLeakyReLU.apply(b, bn_b.weight, bn_b.bias, bn_b, 0.0)
+            f = max_over_tokens(c.view(B * N, k, lin.out_channels))                         # [B*N,Cb]
+            return f.view(B, N, lin.out_channels).transpose(1, 2)
+        return F.relu(conv_b(self._first_conv(x, k, conv_a, norm_plt))).max(dim=-1, keepdim=False)[0]
+
+    def _stage(self, f, sharp, gentle, conv_merge):
         fs, fg = GDM(f, M=512)
         f = torch.cat([sharp(f, fs.transpose(2, 1)), gentle(f, fg.transpose(2, 1))], 1)
         return F.relu(conv_merge(f))
 
     def forward(self, x, norm_plt, cls_label):
         B, C, N = x.size()
-        x1 = self._stage(self._first_conv(x, 30, self.conv1, norm_plt), self.conv11,
+        x1 = self._stage(self._edge_stage(x, 30, self.conv1, self.conv11, norm_plt),
                          self.SGCAM_1s, self.SGCAM_1g, self.conv12)
         x1t = torch.cat((x, x1), dim=1)
-        x2 = self._stage(self._first_conv(x1t, 30, self.conv2), self.conv21,
+        x2 = self._stage(self._edge_stage(x1t, 30, self.conv2, self.conv21),
                          self.SGCAM_2s, self.SGCAM_2g, self.conv22)
         x2t = torch.cat((x1t, x2), dim=1)
-        x3 = F.relu(self.conv31(self._first_conv(x2t, 30, self.conv3))).max(dim=-1, keepdim=False)[0]
-        x3 = F.relu(self.conv32(x3))
+        x3 = F.relu(self.conv32(self._edge_stage(x2t, 30, self.conv3, self.conv31)))
         xx = torch.cat((x1, x2, x3), dim=1)
 
         xc = F.adaptive_max_pool1d(F.relu(self.conv4(xx)), 1).view(B, -1)

@@ -16,6 +16,14 @@ from ... import _native
 USE_NATIVE_TOPK = True
 
 
+# True: in training mode on the GPU a local-operator stage - conv_a, BatchNorm2d, ReLU, conv_b, BatchNorm2d, ReLU, max over
+# the k neighbours (GDANet_ptseg.py:59-60, 66-67, 72) - stays token-major ([B*N*k, C] rows) on libptops' row kernels:
+# BatchNorm over rows + ReLU in one kernel each way (csrc/batchnorm.hip; MIOpen's NCHW BatchNorm ran 6x off the memory
+# roofline on these [16, 64, 512, 30] tensors), the 1x1 conv_b as a GEMM over the rows, max over k with its arg-max
+# (csrc/reduce.hip).  Same function, same running-statistics updates as nn.BatchNorm2d.
+TOKEN_MAJOR_STAGE = os.environ.get("PTOPS_GDANET_TOKEN_MAJOR", "1") != "0"
+
+
 def _topk_indices(pairwise, k):
     if (USE_NATIVE_TOPK and pairwise.is_cuda and pairwise.dtype == torch.float32 and pairwise.size(-1) <= 2048
             and _native.backend_for_testing() is None):
@@ -82,9 +90,10 @@ class _ContiguousGrad(torch.autograd.Function):
         return g.contiguous()
 
 
-def local_conv(x, conv, k, extra=None):
+def local_conv(x, conv, k, extra=None, token_major=False):
     """`conv(local_operator(x, k))` - or, with `extra` = the normals as [B,3,N] channels, `conv(local_operator_withnorm(...))`
-    - for a 1x1 `nn.Conv2d`: x [B,C,N] -> [B,Co,N,k] (reference GDANet_util.py:14-70 followed by GDANet_ptseg.py:59,66,72)."""
+    - for a 1x1 `nn.Conv2d`: x [B,C,N] -> [B,Co,N,k] (reference GDANet_util.py:14-70 followed by GDANet_ptseg.py:59,66,72);
+    `token_major`: the same values as [B,N,k,Co] (one edge = one row of Co channels)."""
     B, C, N = x.shape
     Co = conv.out_channels
     idx, _ = knn(x, k=k)                                                 # [B,N,k] int64
@@ -99,7 +108,7 @@ def local_conv(x, conv, k, extra=None):
     # consecutive threads hit consecutive channels of ONE destination row (0.17 ms) instead of 30-fold contended scalar atomics
     # all over a channel's 512 points (0.74 ms for the 128-channel stage when gathered channel-major)
     y = _ContiguousGrad.apply(_gather_rows(P.transpose(2, 1).contiguous(), idx)) + R.transpose(2, 1).unsqueeze(2)   # [B,N,k,Co]
-    return y.permute(0, 3, 1, 2).contiguous()
+    return y if token_major else y.permute(0, 3, 1, 2).contiguous()
 
 
 def GDM(x, M, device=None):

@@ -164,3 +164,47 @@ def test_chamfer_reductions_on_the_hip_path():
             assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
             grads.append(x.grad.clone())
         assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.gpu
+def test_gdanet_token_major_edge_stage_equals_the_nchw_form(native):
+    """A local-operator stage of GDANet in training mode (reference GDANet_ptseg.py:59-60, 66-67, 72: conv, BatchNorm2d,
+    ReLU, conv, BatchNorm2d, ReLU, max over k) on libptops' row kernels against the same stage on ATen / MIOpen in NCHW:
+    output, gradient of the input and the running statistics of both BatchNorms, for the stage with normals (9 -> 64) and
+    the 262 -> 128 stage."""
+    from imgadapointr_amd.models.segmentation import GDANet_util as U
+    from imgadapointr_amd.models.segmentation.GDANet_ptseg import GDANet
+    torch.manual_seed(0)
+    m = GDANet(50).cuda().train()
+    for p in m.parameters():
+        p.requires_grad = False                                  # frozen, as the runner uses it
+    with torch.no_grad():
+        for bn in (m.bn1, m.bn11, m.bn3, m.bn31):                # non-trivial affine parameters
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    B, N = 4, 512
+    cases = [(3, m.conv1, m.conv11, True), (131, m.conv3, m.conv31, False)]
+    was = U.TOKEN_MAJOR_STAGE
+    try:
+        for C, conv_a, conv_b, with_normals in cases:
+            x = (torch.rand(B, C, N, device="cuda") - 0.5)
+            normals = torch.nn.functional.normalize(torch.randn(B, N, 3, device="cuda"), dim=-1) if with_normals else None
+            w = torch.randn(B, conv_b[0].out_channels, N, device="cuda")
+            got = []
+            for token_major in (False, True):
+                U.TOKEN_MAJOR_STAGE = token_major
+                for bn in (conv_a[1], conv_b[1]):
+                    bn.reset_running_stats()
+                xx = x.clone().requires_grad_(True)
+                f = m._edge_stage(xx, 30, conv_a, conv_b, normals)
+                (f * w).sum().backward()
+                got.append((f.detach().clone(), xx.grad.clone(), conv_a[1].running_mean.clone(), conv_a[1].running_var.clone(),
+                            conv_b[1].running_mean.clone(), conv_b[1].running_var.clone(),
+                            conv_b[1].num_batches_tracked.clone().float()))
+            names = ("output", "input gradient", "bn_a mean", "bn_a var", "bn_b mean", "bn_b var", "batches tracked")
+            for name, a, b in zip(names, *got):
+                err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
+                # fp32 sums in another order; the gradient also sees a handful of arg-max / ReLU decisions at rounding level
+                assert err < (2e-3 if name == "input gradient" else 2e-5), (C, name, err)
+    finally:
+        U.TOKEN_MAJOR_STAGE = was
