@@ -92,8 +92,6 @@ def run_graphed(model, step, spec, n_steps):
         for name, mod in model.named_modules():
             if name:
                 mod.register_forward_hook(hook(name))
-        inner = gs.step.__call__
-
         return e
     gs._capture = capture_then_hook
     real_step = gs.step
