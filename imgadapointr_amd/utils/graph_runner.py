@@ -27,6 +27,25 @@ import torch
 _log = logging.getLogger(__name__)
 
 
+class _no_gemm_tuning:
+    """While a stream is capturing, TunableOp must not TUNE: a GEMM shape it has not seen (inside a capture a weight gradient on a
+    side stream takes the library path, with a shape the eager warm-up steps handed to the grouped launch) would be timed with
+    events and synchronisations, which invalidates the capture (`hipErrorCapturedEvent`).  Untuned shapes take the library's
+    default kernel; tuned selections are still used."""
+
+    def __enter__(self):
+        tun = getattr(torch.cuda, "tunable", None)
+        self._was = bool(tun is not None and tun.is_enabled() and tun.tuning_is_enabled())
+        if self._was:
+            tun.tuning_enable(False)
+        return self
+
+    def __exit__(self, *exc):
+        if self._was:
+            torch.cuda.tunable.tuning_enable(True)
+        return False
+
+
 def _flatten(out):
     if isinstance(out, torch.Tensor):
         return [out], lambda ts: ts[0]
@@ -87,7 +106,7 @@ class GraphedForward:
                     eager = self.model(*static_in)
             torch.cuda.current_stream(device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _no_gemm_tuning(), torch.cuda.graph(graph):
                 out = self.model(*static_in)
         except torch.cuda.OutOfMemoryError:
             raise
@@ -341,7 +360,7 @@ class GraphedTrainStep:
         graph = torch.cuda.CUDAGraph()
         before = torch.cuda.current_stream(device)
         try:
-            with state, torch.cuda.graph(graph), _native.capturing(state):
+            with state, _no_gemm_tuning(), torch.cuda.graph(graph), _native.capturing(state):
                 out = self.step(partial, gt, extra, epoch, noise,
                                 _update=lambda: plan.__setitem__("norm", opt.graph_capture_step(plan, self.step.clip)))
         except torch.cuda.OutOfMemoryError:

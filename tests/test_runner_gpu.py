@@ -427,3 +427,35 @@ def test_graphed_train_step_recaptures_when_a_baked_scalar_changes(native):
     # the changed momentum reached the replayed BatchNorm launches: running statistics follow the eager run
     for n in be:
         assert torch.allclose(be[n], bg[n], rtol=1e-3, atol=1e-5), n
+
+
+@pytest.mark.gpu
+def test_capture_does_not_tune_gemms(native):
+    """A GEMM shape that TunableOp meets for the first time INSIDE a capture (in a captured train step a weight gradient on a
+    side stream takes the library path, which the eager warm-up steps never did: `bench.py --model seg --views 6` lost its
+    graph that way) must not be tuned there: tuning times candidates with events, which invalidates the capture."""
+    from imgadapointr_amd.utils.gemm_tuning import enable_tuned_gemm
+    from imgadapointr_amd.utils.graph_runner import GraphedForward
+    enable_tuned_gemm()
+    tun = torch.cuda.tunable
+    if not (tun.is_enabled() and tun.tuning_is_enabled()):
+        pytest.skip("TunableOp is not tuning in this configuration")
+
+    class ShapeChangesUnderCapture(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(328, 200))
+
+        def forward(self, x):
+            w = self.w[:, :136] if torch.cuda.is_current_stream_capturing() else self.w      # 136: a K no layer of the path has
+            return x[:, :w.size(1)] @ w.t()
+
+    m = ShapeChangesUnderCapture().cuda().eval()
+    gf = GraphedForward(m, verify=False)
+    with torch.no_grad():
+        x = torch.randn(1000, 200, device="cuda")
+        for _ in range(3):
+            out = gf(x)
+        assert gf.enabled, gf.disabled_reason
+        assert torch.allclose(out, x[:, :136] @ m.w[:, :136].t(), rtol=1e-4, atol=1e-4)
+    assert tun.tuning_is_enabled()                            # restored after the capture
