@@ -16,9 +16,10 @@ import re
 FAMILIES = [
     ("ptops: chamfer", r"chamfer_"),
     ("ptops: knn", r"knn_kernel"),
+    ("ptops: top-k rows", r"topk_rows_kernel"),
     ("ptops: fps", r"fps_kernel"),
     ("ptops: edge-conv", r"edge_[a-z_]+kernel"),
-    ("ptops: gather/index", r"gather_|index_points"),
+    ("ptops: gather/index", r"(?<!scatter_)gather_|index_points"),      # not ATen's _scatter_gather_elementwise_kernel
     ("ptops: attention fwd", r"attn_fwd_"),
     ("ptops: attention bwd", r"attn_bwd_|attn_dq_reduce|attn_dkv_reduce"),
     ("ptops: layernorm", r"ln_fwd_kernel|ln_bwd_kernel"),
