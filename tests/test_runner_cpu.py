@@ -262,3 +262,32 @@ def test_graphed_train_step_falls_through_on_cpu_and_private_state_swaps_tables(
             assert _native._colsum_ws == {"inside": 1}
     finally:
         _native._colsum_ws.pop("marker", None)
+
+
+def test_no_gemm_tuning_guard_restores_the_tuning_state(monkeypatch):
+    """`graph_runner._no_gemm_tuning` switches TunableOp's TUNING off for the duration of a capture and back on afterwards,
+    only if it was on; host logic, checked against a stand-in for `torch.cuda.tunable`."""
+    import types
+    import torch
+    from imgadapointr_amd.utils import graph_runner
+    state = {"enabled": True, "tuning": True, "calls": []}
+    fake = types.SimpleNamespace(is_enabled=lambda: state["enabled"], tuning_is_enabled=lambda: state["tuning"],
+                                 tuning_enable=lambda v: (state.__setitem__("tuning", bool(v)), state["calls"].append(bool(v))))
+    monkeypatch.setattr(torch.cuda, "tunable", fake, raising=False)
+    with graph_runner._no_gemm_tuning():
+        assert state["tuning"] is False
+    assert state["tuning"] is True and state["calls"] == [False, True]
+    try:
+        with graph_runner._no_gemm_tuning():
+            raise RuntimeError("capture failed")
+    except RuntimeError:
+        pass
+    assert state["tuning"] is True                         # restored on the error path as well
+    state.update(tuning=False, calls=[])
+    with graph_runner._no_gemm_tuning():
+        pass
+    assert state["calls"] == [] and state["tuning"] is False   # was off: left alone
+    state.update(enabled=False, tuning=True, calls=[])
+    with graph_runner._no_gemm_tuning():
+        pass
+    assert state["calls"] == []                            # TunableOp not in use: left alone
